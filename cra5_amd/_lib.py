@@ -1,0 +1,74 @@
+"""ctypes binding of the in-tree C-ABI library (include/cra5_amd.h).
+
+There is NO fallback: if `libcra5_amd.so` is missing the import of any compute
+entry point raises.  Build it with `python -m cra5_amd.build`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcra5_amd.so")
+
+c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+P = ctypes.POINTER
+
+# name -> (restype, argtypes); mirrors include/cra5_amd.h one to one
+SIGNATURES = {
+    "cra5_abi_version": (c_int, []),
+    "cra5_rans_encode_with_indexes": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                              P(c_void_p), P(c_size_t)]),
+    "cra5_rans_decode_with_indexes": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p,
+                                              c_void_p, c_void_p]),
+    "cra5_rans_encode_batch": (c_int, [c_int, P(c_void_p), P(c_void_p), P(c_size_t), P(c_void_p), P(c_int), P(c_int),
+                                       P(c_void_p), P(c_void_p), P(c_void_p), P(c_size_t), P(c_int), c_int]),
+    "cra5_rans_decode_batch": (c_int, [c_int, P(c_void_p), P(c_size_t), P(c_void_p), P(c_size_t), P(c_void_p), P(c_int),
+                                       P(c_int), P(c_void_p), P(c_void_p), P(c_void_p), P(c_int), c_int]),
+    "cra5_free": (None, [c_void_p]),
+    "cra5_pmf_to_quantized_cdf": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "cra5_gemm_nt_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_int, c_void_p]),
+    "cra5_layernorm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                   c_void_p]),
+    "cra5_window_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_float, c_void_p]),
+    "cra5_im2col_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "cra5_col2im_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "cra5_transpose_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cra5_pixel_shuffle_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cra5_gaussian_conditional_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                              c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cra5_entropy_bottleneck_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_int, c_void_p]),
+    "cra5_gdn_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "cra5_event_create": (c_int, [P(c_void_p)]),
+    "cra5_event_record": (c_int, [c_void_p, c_void_p]),
+    "cra5_event_elapsed_ms": (c_int, [c_void_p, c_void_p, P(c_float)]),
+    "cra5_event_destroy": (c_int, [c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). "
+                "Run `python -m cra5_amd.build` (hipcc, gfx950).")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class Cra5Error(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise Cra5Error(f"{what} failed with status {rc}")

@@ -1,0 +1,399 @@
+// HBM-bound kernels of the VAEformer path: LayerNorm, patch gather / overlap-add scatter
+// (fused with the API's (de)normalisation), layout plumbing, and the two entropy-model
+// kernels (GaussianConditional, EntropyBottleneck) + GDN.  All of them are streaming:
+// coalesced 16-byte accesses, wave64 shuffles for reductions, no atomics (the h_s -> index
+// path must be bit-reproducible between the encode and the decode side).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/cra5_amd.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per row, the row lives in registers (two-pass mean / variance,
+// fixed butterfly reduction order -> deterministic).  vit_nlc.py:266,278 (eps = 1e-6).
+// ---------------------------------------------------------------------------------------
+template <int V4>  // float4 per lane (D <= V4 * 256)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int ldx,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float *__restrict__ y,
+                                                        int ldy, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *xr = x + (size_t)row * ldx;
+  float4 v[V4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < D) v[i] = *reinterpret_cast<const float4 *>(xr + c);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float var = wave_sum(q) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  float *yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4 *>(yr + c) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// im2col (patch gather) with fused normalisation.  One thread per output float; consecutive
+// threads walk the K (= c, i, j) axis of one token -> coalesced stores.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                     const float *__restrict__ stdv, float *__restrict__ cols,
+                                                     int C, int H, int W, int kh, int kw, int sh, int sw,
+                                                     int Hp, int Wp, int ldk) {
+  const int K = C * kh * kw;
+  const size_t total = (size_t)Hp * Wp * K;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int tok = (int)(e / K);
+    const int k = (int)(e - (size_t)tok * K);
+    const int ph = tok / Wp, pw = tok - ph * Wp;
+    const int c = k / (kh * kw);
+    const int ij = k - c * kh * kw;
+    const int i = ij / kw, j = ij - i * kw;
+    float v = x[((size_t)c * H + (ph * sh + i)) * W + (pw * sw + j)];
+    if (mean) v = (v - mean[c]) / stdv[c];
+    cols[(size_t)tok * ldk + k] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// col2im (ConvTranspose2d overlap-add) with fused de-normalisation.  Gather formulation:
+// one thread per output pixel sums its <= ceil(kh/sh)*ceil(kw/sw) contributions in a fixed
+// order -> no atomics, deterministic.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ cols, const float *__restrict__ mean,
+                                                     const float *__restrict__ stdv, float *__restrict__ x, int C,
+                                                     int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp,
+                                                     int ldn) {
+  const size_t total = (size_t)C * H * W;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(e % W);
+    const size_t t = e / W;
+    const int row = (int)(t % H);
+    const int c = (int)(t / H);
+    // patches ph with 0 <= row - ph*sh < kh
+    int ph_hi = row / sh;
+    if (ph_hi > Hp - 1) ph_hi = Hp - 1;
+    int ph_lo = (row - kh + sh) / sh;  // ceil((row-kh+1)/sh) for row-kh+1 >= 0
+    if (row - kh + 1 < 0) ph_lo = 0;
+    int pw_hi = col / sw;
+    if (pw_hi > Wp - 1) pw_hi = Wp - 1;
+    int pw_lo = (col - kw + sw) / sw;
+    if (col - kw + 1 < 0) pw_lo = 0;
+    float acc = 0.f;
+    for (int ph = ph_lo; ph <= ph_hi; ++ph) {
+      const int i = row - ph * sh;
+      for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+        const int j = col - pw * sw;
+        acc += cols[(size_t)(ph * Wp + pw) * ldn + (c * kh + i) * kw + j];
+      }
+    }
+    if (mean) acc = acc * stdv[c] + mean[c];
+    x[e] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// 32x32 LDS-tiled transpose
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int ld_in,
+                                                        float *__restrict__ out, int ld_out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = in[(size_t)r * ld_in + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < rows && c < cols) out[(size_t)c * ld_out + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+// 'b h w (p1 p2 c) -> b c (h p1) (w p2)'
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float *__restrict__ lin, float *__restrict__ out,
+                                                            int Hz, int Wz, int p1, int p2, int Cout) {
+  const int Wo = Wz * p2, Ho = Hz * p1;
+  const size_t total = (size_t)Cout * Ho * Wo;
+  const int F = p1 * p2 * Cout;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int wo = (int)(e % Wo);
+    const size_t t = e / Wo;
+    const int ho = (int)(t % Ho);
+    const int c = (int)(t / Ho);
+    const int hz = ho / p1, a = ho - hz * p1;
+    const int wz = wo / p2, b = wo - wz * p2;
+    out[e] = lin[(size_t)(hz * Wz + wz) * F + (a * p2 + b) * Cout + c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// GaussianConditional (entropy_models.py:645-685).  Phi(u) = 0.5 * erfc(-u / sqrt 2).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float phi(float u) { return 0.5f * erfcf(-0.70710678118654752440f * u); }
+
+__global__ __launch_bounds__(256) void gaussian_conditional_kernel(
+    const float *__restrict__ y, const int32_t *__restrict__ sym_in, const float *__restrict__ scales,
+    const float *__restrict__ means, const float *__restrict__ table, int n_table, float scale_bound,
+    float lik_bound, int32_t *__restrict__ idx, int32_t *__restrict__ sym, float *__restrict__ y_hat,
+    float *__restrict__ lik, size_t n) {
+  __shared__ float tb[256];
+  for (int i = threadIdx.x; i < n_table; i += blockDim.x) tb[i] = table[i];
+  __syncthreads();
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float mu = means[e];
+    const float s = fmaxf(scales[e], scale_bound);  // LowerBound
+    float q;                                        // quantised residual
+    if (y) q = rintf(y[e] - mu);                    // torch.round = half-to-even
+    else q = (float)sym_in[e];
+    if (idx) {
+      int id = n_table - 1;
+      for (int t = 0; t < n_table - 1; ++t) id -= (s <= tb[t]) ? 1 : 0;
+      idx[e] = id;
+    }
+    if (sym) sym[e] = (int32_t)q;
+    const float yh = q + mu;
+    if (y_hat) y_hat[e] = yh;
+    if (lik) {
+      const float v = fabsf(yh - mu);
+      const float up = phi((0.5f - v) / s);
+      const float lo = phi((-0.5f - v) / s);
+      lik[e] = fmaxf(up - lo, lik_bound);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// EntropyBottleneck (entropy_models.py:434-510).  Per-channel parameter block (58 floats):
+//   [ 0: 3) sp(M0)   [ 3: 6) b0   [ 6: 9) th(f0)
+//   [ 9:18) sp(M1)   [18:21) b1   [21:24) th(f1)
+//   [24:33) sp(M2)   [33:36) b2   [36:39) th(f2)
+//   [39:48) sp(M3)   [48:51) b3   [51:54) th(f3)
+//   [54:57) sp(M4)   [57]    b4
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float eb_logits(const float *p, float v) {
+  float a[3], b[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    a[i] = p[i] * v + p[3 + i];
+    a[i] += p[6 + i] * tanhf(a[i]);
+  }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const float *m = p + 9 + 15 * l;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float t = m[3 * i + 0] * a[0];
+      t += m[3 * i + 1] * a[1];
+      t += m[3 * i + 2] * a[2];
+      t += m[9 + i];
+      b[i] = t + m[12 + i] * tanhf(t);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = b[i];
+  }
+  float t = p[54] * a[0];
+  t += p[55] * a[1];
+  t += p[56] * a[2];
+  return t + p[57];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void entropy_bottleneck_kernel(
+    const float *__restrict__ z, const int32_t *__restrict__ sym_in, const float *__restrict__ medians,
+    const float *__restrict__ params, float lik_bound, int32_t *__restrict__ sym, float *__restrict__ z_hat,
+    float *__restrict__ lik, int C, int n_per_ch) {
+  const size_t total = (size_t)C * n_per_ch;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e / n_per_ch);
+    const float med = medians[c];
+    float q;
+    if (z) q = rintf(z[e] - med);
+    else q = (float)sym_in[e];
+    if (sym) sym[e] = (int32_t)q;
+    const float zh = q + med;
+    if (z_hat) z_hat[e] = zh;
+    if (lik) {
+      const float *p = params + 58 * c;
+      const float lo = eb_logits(p, zh - 0.5f);
+      const float up = eb_logits(p, zh + 0.5f);
+      lik[e] = fmaxf(sigmoidf_(up) - sigmoidf_(lo), lik_bound);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// GDN / IGDN (layers/gdn.py:76-92): per pixel a C x C mat-vec on x^2.  One thread per
+// (b, pixel, out-channel); the x^2 vector of the pixel is shared through LDS.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gdn_kernel(const float *__restrict__ x, const float *__restrict__ beta,
+                                                  const float *__restrict__ gamma, float *__restrict__ y, int B,
+                                                  int C, int HW, int inverse) {
+  extern __shared__ float sq[];  // [PIX][C]
+  const int PIX = 256 / 64 * 16; // 64 pixels per block
+  const int p0 = blockIdx.x * PIX;
+  const int b = blockIdx.y;
+  const float *xb = x + (size_t)b * C * HW;
+  float *yb = y + (size_t)b * C * HW;
+  for (int e = threadIdx.x; e < PIX * C; e += blockDim.x) {
+    const int c = e / PIX, p = e - c * PIX;
+    const float v = (p0 + p < HW) ? xb[(size_t)c * HW + p0 + p] : 0.f;
+    sq[p * C + c] = v * v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < PIX * C; e += blockDim.x) {
+    const int c = e / PIX, p = e - c * PIX;
+    if (p0 + p >= HW) continue;
+    float n = beta[c];
+    const float *gr = gamma + (size_t)c * C;
+    const float *s = sq + p * C;
+    for (int j = 0; j < C; ++j) n += gr[j] * s[j];
+    const float xv = xb[(size_t)c * HW + p0 + p];
+    yb[(size_t)c * HW + p0 + p] = inverse ? xv * sqrtf(n) : xv * (1.0f / sqrtf(n));
+  }
+}
+
+inline int grid_for(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  const size_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
+  return (int)(g < cap ? (g ? g : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float *beta, float *y, int ldy, int rows,
+                       int D, float eps, void *stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (ldy & 3) || D > 2048)
+    return CRA5_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+  return (int)hipGetLastError();
+}
+
+int cra5_im2col_f32(const float *x, const float *mean, const float *stdv, float *cols, int C, int H, int W, int kh,
+                    int kw, int sh, int sw, int Hp, int Wp, int ldk, void *stream) {
+  if (!x || !cols || C <= 0 || ldk < C * kh * kw) return CRA5_ERR_ARG;
+  if ((Hp - 1) * sh + kh > H || (Wp - 1) * sw + kw > W) return CRA5_ERR_ARG;
+  if ((mean == nullptr) != (stdv == nullptr)) return CRA5_ERR_ARG;
+  const size_t total = (size_t)Hp * Wp * C * kh * kw;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, cols, C,
+                     H, W, kh, kw, sh, sw, Hp, Wp, ldk);
+  return (int)hipGetLastError();
+}
+
+int cra5_col2im_f32(const float *cols, const float *mean, const float *stdv, float *x, int C, int H, int W, int kh,
+                    int kw, int sh, int sw, int Hp, int Wp, int ldn, void *stream) {
+  if (!x || !cols || C <= 0 || ldn < C * kh * kw) return CRA5_ERR_ARG;
+  if ((Hp - 1) * sh + kh != H || (Wp - 1) * sw + kw != W) return CRA5_ERR_ARG;
+  if ((mean == nullptr) != (stdv == nullptr)) return CRA5_ERR_ARG;
+  const size_t total = (size_t)C * H * W;
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, cols, mean, stdv, x, C,
+                     H, W, kh, kw, sh, sw, Hp, Wp, ldn);
+  return (int)hipGetLastError();
+}
+
+int cra5_transpose_f32(const float *in, int ld_in, float *out, int ld_out, int rows, int cols, void *stream) {
+  if (!in || !out || rows <= 0 || cols <= 0) return CRA5_ERR_ARG;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+  hipLaunchKernelGGL(transpose_kernel, grid, block, 0, (hipStream_t)stream, in, ld_in, out, ld_out, rows, cols);
+  return (int)hipGetLastError();
+}
+
+int cra5_pixel_shuffle_f32(const float *lin, float *out, int Hz, int Wz, int p1, int p2, int Cout, void *stream) {
+  if (!lin || !out || Hz <= 0 || Wz <= 0 || p1 <= 0 || p2 <= 0 || Cout <= 0) return CRA5_ERR_ARG;
+  const size_t total = (size_t)Cout * Hz * p1 * Wz * p2;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, lin, out, Hz, Wz,
+                     p1, p2, Cout);
+  return (int)hipGetLastError();
+}
+
+int cra5_gaussian_conditional_f32(const float *y, const int32_t *sym_in, const float *scales, const float *means,
+                                  const float *scale_table, int n_table, float scale_bound, float lik_bound,
+                                  int32_t *idx, int32_t *sym, float *y_hat, float *lik, size_t n, void *stream) {
+  if ((!y && !sym_in) || !scales || !means || n == 0) return CRA5_ERR_ARG;
+  if (idx && (!scale_table || n_table < 1 || n_table > 256)) return CRA5_ERR_ARG;
+  hipLaunchKernelGGL(gaussian_conditional_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, sym_in,
+                     scales, means, scale_table, idx ? n_table : 0, scale_bound, lik_bound, idx, sym, y_hat, lik, n);
+  return (int)hipGetLastError();
+}
+
+int cra5_entropy_bottleneck_f32(const float *z, const int32_t *sym_in, const float *medians, const float *params,
+                                float lik_bound, int32_t *sym, float *z_hat, float *lik, int C, int n_per_ch,
+                                void *stream) {
+  if ((!z && !sym_in) || !medians || C <= 0 || n_per_ch <= 0) return CRA5_ERR_ARG;
+  if (lik && !params) return CRA5_ERR_ARG;
+  hipLaunchKernelGGL(entropy_bottleneck_kernel, dim3(grid_for((size_t)C * n_per_ch)), dim3(256), 0,
+                     (hipStream_t)stream, z, sym_in, medians, params, lik_bound, sym, z_hat, lik, C, n_per_ch);
+  return (int)hipGetLastError();
+}
+
+int cra5_gdn_f32(const float *x, const float *beta, const float *gamma, float *y, int B, int C, int HW, int inverse,
+                 void *stream) {
+  if (!x || !beta || !gamma || !y || B <= 0 || C <= 0 || HW <= 0 || C > 512) return CRA5_ERR_ARG;
+  const int PIX = 64;
+  dim3 grid((HW + PIX - 1) / PIX, B), block(256);
+  hipLaunchKernelGGL(gdn_kernel, grid, block, (size_t)PIX * C * sizeof(float), (hipStream_t)stream, x, beta, gamma, y,
+                     B, C, HW, inverse);
+  return (int)hipGetLastError();
+}
+
+int cra5_event_create(void **ev) {
+  hipEvent_t e;
+  const int rc = (int)hipEventCreate(&e);
+  *ev = (void *)e;
+  return rc;
+}
+int cra5_event_record(void *ev, void *stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+int cra5_event_elapsed_ms(void *start, void *stop, float *ms) {
+  int rc = (int)hipEventSynchronize((hipEvent_t)stop);
+  if (rc) return rc;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+int cra5_event_destroy(void *ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+// Host-side entropy coding for the cra5_amd C ABI (include/cra5_amd.h).
+//
+// rANS64 coder with the wire semantics of the reference's `compressai.ans`
+// (rans_interface.cpp:108-284 in taohan10200/CRA5: 16-bit probabilities, escape bin +
+// 4-bit bypass nibbles, symbols coded in reverse, 32-bit little-endian word stream) and
+// the pmf -> quantised-CDF routine of `compressai._CXX` (ops.cpp:40-108).
+//
+// Design differences from the reference (same bytes out):
+//   * flat int32 arrays in, no Python-list marshalling, no GIL, no global state;
+//   * the encoder never materialises the (start, range, bypass) symbol vector: one
+//     counting pass sizes the word buffer, then one backward pass codes straight from
+//     the symbol array (bypass nibbles are regenerated in reverse order);
+//   * the decoder finds the bin with a binary search instead of the reference's linear
+//     `find_if` scan (identical result on a strictly increasing CDF row);
+//   * range-checked: bad table indexes / truncated streams return an error code.
+#include "../../include/cra5_amd.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint64_t kRansL = 1ull << 31;  // rans64.h RANS64_L
+constexpr uint32_t kProbBits = 16;       // rans_interface.cpp:49
+constexpr uint32_t kBypassBits = 4;      // rans_interface.cpp:51
+constexpr uint32_t kBypassMax = (1u << kBypassBits) - 1;
+
+struct Tables {
+  const int32_t *cdfs;
+  int n_cdfs;
+  int stride;
+  const int32_t *sizes;
+  const int32_t *offsets;
+};
+
+// One coded symbol resolved against its table: bin + escape payload.
+struct Resolved {
+  uint32_t start, range;
+  bool escape;
+  uint32_t raw;
+  int n_nibbles;
+};
+
+inline int nibbles_of(uint32_t raw) {
+  int n = 0;
+  while (n < 8 && (raw >> (n * kBypassBits)) != 0) ++n;
+  return n;
+}
+
+inline Resolved resolve(const Tables &t, int32_t sym, int32_t ci) {
+  const int32_t *cdf = t.cdfs + static_cast<size_t>(ci) * t.stride;
+  const int32_t max_value = t.sizes[ci] - 2;
+  int32_t value = sym - t.offsets[ci];
+  Resolved r{0, 0, false, 0, 0};
+  if (value < 0) {
+    r.raw = static_cast<uint32_t>(-2 * value - 1);
+    value = max_value;
+  } else if (value >= max_value) {
+    r.raw = static_cast<uint32_t>(2 * (value - max_value));
+    value = max_value;
+  }
+  r.start = static_cast<uint32_t>(cdf[value]) & 0xFFFFu;
+  r.range = static_cast<uint32_t>(cdf[value + 1] - cdf[value]) & 0xFFFFu;
+  if (value == max_value) {
+    r.escape = true;
+    r.n_nibbles = nibbles_of(r.raw);
+  }
+  return r;
+}
+
+struct Encoder {
+  uint64_t x = kRansL;
+  uint32_t *ptr;
+  inline void put(uint32_t start, uint32_t freq) {
+    const uint64_t x_max = ((kRansL >> kProbBits) << 32) * freq;
+    if (x >= x_max) {
+      *--ptr = static_cast<uint32_t>(x);
+      x >>= 32;
+    }
+    x = ((x / freq) << kProbBits) + (x % freq) + start;
+  }
+  inline void put_bits(uint32_t val) {  // 4-bit bypass symbol
+    constexpr uint32_t freq = 1u << (16 - kBypassBits);
+    constexpr uint64_t x_max = ((kRansL >> 16) << 32) * freq;
+    if (x >= x_max) {
+      *--ptr = static_cast<uint32_t>(x);
+      x >>= 32;
+    }
+    x = (x << kBypassBits) | val;
+  }
+};
+
+int encode_impl(const int32_t *symbols, const int32_t *indexes, size_t n, const Tables &t,
+                uint8_t **out, size_t *out_len) {
+  if (!out || !out_len || (n && (!symbols || !indexes))) return CRA5_ERR_ARG;
+  // pass 1: validate + count coded sub-symbols (each emits at most one word)
+  size_t n_sub = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t ci = indexes[i];
+    if (ci < 0 || ci >= t.n_cdfs || t.sizes[ci] < 2 || t.sizes[ci] > t.stride) return CRA5_ERR_INDEX;
+    const Resolved r = resolve(t, symbols[i], ci);
+    n_sub += 1;
+    if (r.escape) n_sub += static_cast<size_t>(r.n_nibbles) / kBypassMax + 1 + r.n_nibbles;
+  }
+  const size_t cap = n_sub + 2;
+  uint32_t *buf = static_cast<uint32_t *>(std::malloc(cap * sizeof(uint32_t)));
+  if (!buf) return CRA5_ERR_ALLOC;
+  Encoder e;
+  e.ptr = buf + cap;
+  // pass 2: last symbol first; inside a symbol the reference pushes
+  // [bin, count nibbles (15,15,..,rem), payload nibbles lsb-first] and pops in reverse.
+  for (size_t i = n; i-- > 0;) {
+    const Resolved r = resolve(t, symbols[i], indexes[i]);
+    if (r.escape) {
+      for (int j = r.n_nibbles - 1; j >= 0; --j) e.put_bits((r.raw >> (j * kBypassBits)) & kBypassMax);
+      const uint32_t full = static_cast<uint32_t>(r.n_nibbles) / kBypassMax;
+      e.put_bits(static_cast<uint32_t>(r.n_nibbles) - full * kBypassMax);
+      for (uint32_t k = 0; k < full; ++k) e.put_bits(kBypassMax);
+    }
+    e.put(r.start, r.range);
+  }
+  e.ptr -= 2;  // Rans64EncFlush
+  e.ptr[0] = static_cast<uint32_t>(e.x);
+  e.ptr[1] = static_cast<uint32_t>(e.x >> 32);
+  const size_t nbytes = static_cast<size_t>((buf + cap) - e.ptr) * sizeof(uint32_t);
+  uint8_t *res = static_cast<uint8_t *>(std::malloc(nbytes));
+  if (!res) {
+    std::free(buf);
+    return CRA5_ERR_ALLOC;
+  }
+  std::memcpy(res, e.ptr, nbytes);
+  std::free(buf);
+  *out = res;
+  *out_len = nbytes;
+  return CRA5_OK;
+}
+
+struct Decoder {
+  uint64_t x;
+  const uint8_t *p, *end;
+  bool ok = true;
+  inline uint32_t word() {
+    if (p + 4 > end) {
+      ok = false;
+      return 0;
+    }
+    uint32_t w;
+    std::memcpy(&w, p, 4);  // no alignment assumption (the reference casts in place)
+    p += 4;
+    return w;
+  }
+  inline uint32_t get_bits() {
+    const uint32_t val = static_cast<uint32_t>(x & kBypassMax);
+    x >>= kBypassBits;
+    if (x < kRansL) x = (x << 32) | word();
+    return val;
+  }
+};
+
+int decode_impl(const uint8_t *enc, size_t len, const int32_t *indexes, size_t n, const Tables &t,
+                int32_t *out) {
+  if ((n && (!indexes || !out)) || !enc) return CRA5_ERR_ARG;
+  if (len < 8) return CRA5_ERR_STREAM;
+  Decoder d;
+  d.p = enc;
+  d.end = enc + len;
+  const uint64_t lo = d.word();
+  const uint64_t hi = d.word();
+  d.x = lo | (hi << 32);
+  constexpr uint64_t mask = (1ull << kProbBits) - 1;
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t ci = indexes[i];
+    if (ci < 0 || ci >= t.n_cdfs || t.sizes[ci] < 2 || t.sizes[ci] > t.stride) return CRA5_ERR_INDEX;
+    const int32_t *cdf = t.cdfs + static_cast<size_t>(ci) * t.stride;
+    const int32_t csz = t.sizes[ci];
+    const int32_t max_value = csz - 2;
+    const int32_t cum = static_cast<int32_t>(d.x & mask);
+    // first entry > cum, minus one  (== the reference's linear find_if, :246-250)
+    const int32_t s = static_cast<int32_t>(std::upper_bound(cdf, cdf + csz, cum) - cdf) - 1;
+    if (s < 0 || s > max_value) return CRA5_ERR_STREAM;
+    const uint32_t start = static_cast<uint32_t>(cdf[s]);
+    const uint32_t freq = static_cast<uint32_t>(cdf[s + 1] - cdf[s]);
+    d.x = freq * (d.x >> kProbBits) + (d.x & mask) - start;
+    if (d.x < kRansL) d.x = (d.x << 32) | d.word();
+    int32_t value = s;
+    if (value == max_value) {
+      uint32_t val = d.get_bits();
+      int32_t n_bypass = static_cast<int32_t>(val);
+      while (val == kBypassMax && d.ok) {
+        val = d.get_bits();
+        n_bypass += static_cast<int32_t>(val);
+      }
+      if (n_bypass > 8) return CRA5_ERR_STREAM;  // a uint32 payload has at most 8 nibbles
+      uint32_t raw = 0;
+      for (int j = 0; j < n_bypass; ++j) raw |= d.get_bits() << (j * kBypassBits);
+      value = static_cast<int32_t>(raw >> 1);
+      if (raw & 1u) value = -value - 1;
+      else value += max_value;
+    }
+    if (!d.ok) return CRA5_ERR_STREAM;
+    out[i] = value + t.offsets[ci];
+  }
+  return CRA5_OK;
+}
+
+template <class F>
+void parallel_for(int n, int n_threads, F &&f) {
+  if (n_threads <= 1 || n <= 1) {
+    for (int i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<int> next{0};
+  std::vector<std::thread> pool;
+  const int nt = std::min(n_threads, n);
+  pool.reserve(nt);
+  for (int t = 0; t < nt; ++t)
+    pool.emplace_back([&] {
+      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+    });
+  for (auto &th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cra5_abi_version(void) { return 1; }
+
+int cra5_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, size_t n,
+                                  const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                                  const int32_t *cdf_sizes, const int32_t *offsets, uint8_t **out,
+                                  size_t *out_len) {
+  if (!cdfs || !cdf_sizes || !offsets || n_cdfs <= 0 || cdf_stride < 2) return CRA5_ERR_ARG;
+  return encode_impl(symbols, indexes, n, Tables{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets}, out, out_len);
+}
+
+int cra5_rans_decode_with_indexes(const uint8_t *encoded, size_t len, const int32_t *indexes, size_t n,
+                                  const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                                  const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out) {
+  if (!cdfs || !cdf_sizes || !offsets || n_cdfs <= 0 || cdf_stride < 2) return CRA5_ERR_ARG;
+  return decode_impl(encoded, len, indexes, n, Tables{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets}, out);
+}
+
+int cra5_rans_encode_batch(int n_streams, const int32_t *const *symbols, const int32_t *const *indexes,
+                           const size_t *n, const int32_t *const *cdfs, const int *n_cdfs,
+                           const int *cdf_stride, const int32_t *const *cdf_sizes,
+                           const int32_t *const *offsets, uint8_t **out, size_t *out_len, int *rc,
+                           int n_threads) {
+  if (n_streams < 0 || !rc) return CRA5_ERR_ARG;
+  parallel_for(n_streams, n_threads, [&](int i) {
+    rc[i] = cra5_rans_encode_with_indexes(symbols[i], indexes[i], n[i], cdfs[i], n_cdfs[i], cdf_stride[i],
+                                          cdf_sizes[i], offsets[i], &out[i], &out_len[i]);
+  });
+  for (int i = 0; i < n_streams; ++i)
+    if (rc[i]) return rc[i];
+  return CRA5_OK;
+}
+
+int cra5_rans_decode_batch(int n_streams, const uint8_t *const *encoded, const size_t *len,
+                           const int32_t *const *indexes, const size_t *n, const int32_t *const *cdfs,
+                           const int *n_cdfs, const int *cdf_stride, const int32_t *const *cdf_sizes,
+                           const int32_t *const *offsets, int32_t *const *out, int *rc, int n_threads) {
+  if (n_streams < 0 || !rc) return CRA5_ERR_ARG;
+  parallel_for(n_streams, n_threads, [&](int i) {
+    rc[i] = cra5_rans_decode_with_indexes(encoded[i], len[i], indexes[i], n[i], cdfs[i], n_cdfs[i],
+                                          cdf_stride[i], cdf_sizes[i], offsets[i], out[i]);
+  });
+  for (int i = 0; i < n_streams; ++i)
+    if (rc[i]) return rc[i];
+  return CRA5_OK;
+}
+
+void cra5_free(void *p) { std::free(p); }
+
+int cra5_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf) {
+  if (!pmf || !cdf || n <= 0 || precision < 1 || precision > 16) return CRA5_ERR_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!(pmf[i] >= 0.0f) || !std::isfinite(pmf[i])) return CRA5_ERR_PMF_DOMAIN;
+  const float one = static_cast<float>(1 << precision);
+  // frequencies first (kept separately so the fix-up below can work on widths)
+  std::vector<uint32_t> freq(static_cast<size_t>(n));
+  int total_i = 0;  // the reference accumulates into an `int` (std::accumulate(.., 0))
+  for (int i = 0; i < n; ++i) {
+    freq[i] = static_cast<uint32_t>(std::round(pmf[i] * one));
+    total_i = static_cast<int>(static_cast<unsigned>(total_i) + freq[i]);
+  }
+  const uint32_t total = static_cast<uint32_t>(total_i);
+  if (total == 0) return CRA5_ERR_PMF_ZERO;
+  cdf[0] = 0;
+  uint32_t run = 0;
+  for (int i = 0; i < n; ++i) {
+    run += static_cast<uint32_t>((static_cast<uint64_t>(1u << precision) * freq[i]) / total);
+    cdf[i + 1] = run;
+  }
+  cdf[n] = 1u << precision;
+  // zero-width bins steal one count from the narrowest bin that is wider than 1
+  // (first such bin on ties), shifting the boundaries in between (ops.cpp:74-100)
+  for (int i = 0; i < n; ++i) {
+    if (cdf[i] != cdf[i + 1]) continue;
+    uint32_t best = ~0u;
+    int donor = -1;
+    for (int j = 0; j < n; ++j) {
+      const uint32_t w = cdf[j + 1] - cdf[j];
+      if (w > 1 && w < best) {
+        best = w;
+        donor = j;
+      }
+    }
+    if (donor < 0) return CRA5_ERR_PMF_STEAL;
+    if (donor < i) {
+      for (int j = donor + 1; j <= i; ++j) --cdf[j];
+    } else {
+      for (int j = i + 1; j <= donor; ++j) ++cdf[j];
+    }
+  }
+  return CRA5_OK;
+}
+
+}  // extern "C"

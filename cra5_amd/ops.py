@@ -1,0 +1,224 @@
+"""Thin Python launchers over the C ABI.  torch tensors are containers only: every
+function passes raw `data_ptr()`s + sizes + the current HIP stream to the native
+library.  Device entry points refuse non-GPU tensors (no CPU fallback)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+EPI_BIAS, EPI_GELU, EPI_RES = 1, 2, 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("cra5_amd device op called with a non-GPU tensor: the HIP path is the only path "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure)")
+        if t.dtype not in (torch.float32, torch.int32):
+            raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _row_stride(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a 2-D tensor with unit inner stride"
+    return t.stride(0)
+
+
+def gemm_nt(a, w, bias=None, res=None, gelu=False, out=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T).  a / w / res / out may be row-strided views."""
+    _dev(a, w, bias, res, out)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
+    check(lib().cra5_gemm_nt_f32(_p(a), _row_stride(a), _p(w), _row_stride(w), _p(out), _row_stride(out), _p(bias),
+                                 _p(res), _row_stride(res) if res is not None else 0, M, N, K, flags, _stream()),
+          "cra5_gemm_nt_f32")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-6, out=None):
+    _dev(x, gamma, beta, out)
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, D), device=x.device, dtype=torch.float32)
+    check(lib().cra5_layernorm_f32(_p(x), _row_stride(x), _p(gamma), _p(beta), _p(out), _row_stride(out), rows, D,
+                                   float(eps), _stream()), "cra5_layernorm_f32")
+    return out
+
+
+def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None):
+    """qkv: [H*W, 3C] contiguous; returns [H*W, C]."""
+    _dev(qkv, pad_row, out)
+    N, C3 = qkv.shape
+    C = C3 // 3
+    assert N == H * W and qkv.is_contiguous() and pad_row.numel() == C3
+    if out is None:
+        out = torch.empty((N, C), device=qkv.device, dtype=torch.float32)
+    assert out.is_contiguous()
+    scale = float((C // heads) ** -0.5)
+    check(lib().cra5_window_attention_f32(_p(qkv), _p(pad_row), _p(out), C, heads, H, W, wh, ww, scale, _stream()),
+          "cra5_window_attention_f32")
+    return out
+
+
+def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None):
+    """x: [C,H,W] -> cols [Hp*Wp, ldk] (column (c*kh+i)*kw+j); pad columns are zero."""
+    _dev(x, mean, std, out)
+    C, H, W = x.shape
+    Hp, Wp = (H - kh) // sh + 1, (W - kw) // sw + 1
+    K = C * kh * kw
+    ldk = ldk or K
+    if out is None:
+        out = torch.zeros((Hp * Wp, ldk), device=x.device, dtype=torch.float32)
+    assert x.is_contiguous() and out.is_contiguous() and out.shape[1] == ldk
+    check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), _p(out), C, H, W, kh, kw, sh, sw, Hp, Wp, ldk, _stream()),
+          "cra5_im2col_f32")
+    return out
+
+
+def col2im(cols, C, kh, kw, sh, sw, Hp, Wp, mean=None, std=None, out=None):
+    _dev(cols, mean, std, out)
+    H, W = (Hp - 1) * sh + kh, (Wp - 1) * sw + kw
+    if out is None:
+        out = torch.empty((C, H, W), device=cols.device, dtype=torch.float32)
+    assert out.is_contiguous()
+    check(lib().cra5_col2im_f32(_p(cols), _p(mean), _p(std), _p(out), C, H, W, kh, kw, sh, sw, Hp, Wp,
+                                _row_stride(cols), _stream()), "cra5_col2im_f32")
+    return out
+
+
+def transpose(x, out=None):
+    _dev(x, out)
+    R, Cc = x.shape
+    if out is None:
+        out = torch.empty((Cc, R), device=x.device, dtype=torch.float32)
+    check(lib().cra5_transpose_f32(_p(x), _row_stride(x), _p(out), _row_stride(out), R, Cc, _stream()),
+          "cra5_transpose_f32")
+    return out
+
+
+def pixel_shuffle(lin, Hz, Wz, p1, p2, out=None):
+    _dev(lin, out)
+    F = lin.shape[1]
+    Cout = F // (p1 * p2)
+    assert lin.is_contiguous() and lin.shape[0] == Hz * Wz
+    if out is None:
+        out = torch.empty((Cout, Hz * p1, Wz * p2), device=lin.device, dtype=torch.float32)
+    check(lib().cra5_pixel_shuffle_f32(_p(lin), _p(out), Hz, Wz, p1, p2, Cout, _stream()), "cra5_pixel_shuffle_f32")
+    return out
+
+
+def gaussian_conditional(scales, means, scale_table, y=None, sym_in=None, want=("idx", "sym", "y_hat"),
+                         scale_bound=0.11, lik_bound=1e-9):
+    """Fused GC kernel. Returns dict with the requested outputs (flat views shaped like `means`)."""
+    _dev(scales, means, scale_table, y, sym_in)
+    assert scales.is_contiguous() and means.is_contiguous()
+    n = means.numel()
+    dev = means.device
+    o = {}
+    o["idx"] = torch.empty(means.shape, device=dev, dtype=torch.int32) if "idx" in want else None
+    o["sym"] = torch.empty(means.shape, device=dev, dtype=torch.int32) if "sym" in want else None
+    o["y_hat"] = torch.empty(means.shape, device=dev, dtype=torch.float32) if "y_hat" in want else None
+    o["lik"] = torch.empty(means.shape, device=dev, dtype=torch.float32) if "lik" in want else None
+    if y is not None:
+        assert y.is_contiguous() and y.numel() == n
+    if sym_in is not None:
+        assert sym_in.is_contiguous() and sym_in.numel() == n and sym_in.dtype == torch.int32
+    check(lib().cra5_gaussian_conditional_f32(_p(y), _p(sym_in), _p(scales), _p(means), _p(scale_table),
+                                              scale_table.numel(), float(scale_bound), float(lik_bound), _p(o["idx"]),
+                                              _p(o["sym"]), _p(o["y_hat"]), _p(o["lik"]), n, _stream()),
+          "cra5_gaussian_conditional_f32")
+    return {k: v for k, v in o.items() if v is not None}
+
+
+def entropy_bottleneck(medians, params, z=None, sym_in=None, want=("sym", "z_hat"), lik_bound=1e-9, shape=None):
+    """z / sym_in: [C, n] (channel-major)."""
+    _dev(medians, params, z, sym_in)
+    src = z if z is not None else sym_in
+    C = medians.numel()
+    n_per = src.numel() // C
+    dev = src.device
+    o = {}
+    o["sym"] = torch.empty(src.shape, device=dev, dtype=torch.int32) if "sym" in want else None
+    o["z_hat"] = torch.empty(src.shape, device=dev, dtype=torch.float32) if "z_hat" in want else None
+    o["lik"] = torch.empty(src.shape, device=dev, dtype=torch.float32) if "lik" in want else None
+    assert src.is_contiguous()
+    check(lib().cra5_entropy_bottleneck_f32(_p(z), _p(sym_in), _p(medians), _p(params), float(lik_bound), _p(o["sym"]),
+                                            _p(o["z_hat"]), _p(o["lik"]), C, n_per, _stream()),
+          "cra5_entropy_bottleneck_f32")
+    return {k: v for k, v in o.items() if v is not None}
+
+
+def gdn(x, beta_eff, gamma_eff, inverse=False):
+    _dev(x, beta_eff, gamma_eff)
+    B, C = x.shape[:2]
+    HW = x.numel() // (B * C)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib().cra5_gdn_f32(_p(x), _p(beta_eff), _p(gamma_eff), _p(y), B, C, HW, int(bool(inverse)), _stream()),
+          "cra5_gdn_f32")
+    return y
+
+
+# ------------------------------------------------------------------ host entropy coding
+
+
+def _np_i32(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def rans_encode(symbols, indexes, cdf, cdf_len, offsets):
+    """-> bytes. Arguments: int32 arrays (numpy or CPU tensors); cdf is [n_cdfs, stride]."""
+    s, i = _np_i32(symbols).reshape(-1), _np_i32(indexes).reshape(-1)
+    c, l, o = _np_i32(cdf), _np_i32(cdf_len).reshape(-1), _np_i32(offsets).reshape(-1)
+    if s.size != i.size:
+        raise ValueError("`symbols` and `indexes` should have the same size.")
+    out = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    check(lib().cra5_rans_encode_with_indexes(s.ctypes.data, i.ctypes.data, s.size, c.ctypes.data, c.shape[0],
+                                              c.shape[1], l.ctypes.data, o.ctypes.data, ctypes.byref(out),
+                                              ctypes.byref(n)), "cra5_rans_encode_with_indexes")
+    try:
+        return ctypes.string_at(out.value, n.value)
+    finally:
+        lib().cra5_free(out)
+
+
+def rans_decode(data, indexes, cdf, cdf_len, offsets):
+    """-> int32 numpy array of len(indexes)."""
+    i = _np_i32(indexes).reshape(-1)
+    c, l, o = _np_i32(cdf), _np_i32(cdf_len).reshape(-1), _np_i32(offsets).reshape(-1)
+    out = np.empty(i.size, dtype=np.int32)
+    buf = (ctypes.c_char * len(data)).from_buffer_copy(data)
+    check(lib().cra5_rans_decode_with_indexes(ctypes.addressof(buf), len(data), i.ctypes.data, i.size, c.ctypes.data,
+                                              c.shape[0], c.shape[1], l.ctypes.data, o.ctypes.data, out.ctypes.data),
+          "cra5_rans_decode_with_indexes")
+    return out
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    p = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
+    out = np.empty(p.size + 1, dtype=np.uint32)
+    rc = lib().cra5_pmf_to_quantized_cdf(p.ctypes.data, p.size, precision, out.ctypes.data)
+    if rc in (-3, -4, -5):
+        raise ValueError({-3: "Invalid `pmf`, non-finite or negative element found",
+                          -4: "Invalid `pmf`: at least one element must have a non-zero probability.",
+                          -5: "Invalid `pmf`: no bin can donate frequency"}[rc])
+    check(rc, "cra5_pmf_to_quantized_cdf")
+    return out

@@ -1,0 +1,93 @@
+"""Deterministic synthetic weights.
+
+There is no network on the build / GPU boxes, so neither the reference checkpoint
+(`cra5_268v_300k.pth`, zoo/image.py:73 in the reference) nor ERA5 samples exist.
+`fill_state_dict` produces closed-form, seed-reproducible values for every
+parameter of a VAEformer state dict (reference key names), scaled so that the
+entropy-coding side is exercised (scale indexes spread over the table, non-zero
+symbols, a few escape symbols).  bench.py, the tests and the golden-vector generator
+all call this one function, so the same weights can be rebuilt anywhere without
+shipping tensors.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+_SKIP = ("._offset", "._quantized_cdf", "._cdf_length", ".scale_table", ".scale_bound", ".bound", ".target")
+
+
+def _rng(seed, key):
+    return np.random.default_rng([int(seed) & 0x7FFFFFFF, zlib.crc32(key.encode())])
+
+
+def _randn(rng, shape, std):
+    return torch.from_numpy((rng.standard_normal(size=tuple(shape), dtype=np.float32) * np.float32(std)))
+
+
+def synth_tensor(key, shape, seed=0):
+    """Value of parameter `key` (reference naming) with `shape`; None = leave as is."""
+    if key.endswith(_SKIP):
+        return None
+    rng = _rng(seed, key)
+    shape = tuple(shape)
+    leaf = key.rsplit(".", 1)[-1]
+    if key.startswith("entropy_bottleneck."):
+        C = shape[0]
+        if leaf.startswith("_matrix"):
+            i = int(leaf[-1])
+            filters = (1, 3, 3, 3, 3, 1)
+            scale = 10.0 ** (1 / 5)
+            init = float(np.log(np.expm1(1 / scale / filters[i + 1])))
+            return init + _randn(rng, shape, 0.1)
+        if leaf.startswith("_bias"):
+            return torch.from_numpy(rng.uniform(-0.5, 0.5, size=shape).astype(np.float32))
+        if leaf.startswith("_factor"):
+            return _randn(rng, shape, 0.1)
+        if leaf == "quantiles":
+            med = rng.standard_normal(C).astype(np.float32) * 0.3
+            lo = med - 4.0 * (1 + 0.3 * rng.random(C).astype(np.float32))
+            hi = med + 4.0 * (1 + 0.3 * rng.random(C).astype(np.float32))
+            return torch.from_numpy(np.stack([lo, med, hi], -1).reshape(C, 1, 3))
+        return None
+    if leaf == "pos_embed":
+        return _randn(rng, shape, 0.2)
+    if ".norm" in key and leaf == "weight" and len(shape) == 1:
+        return 1.0 + _randn(rng, shape, 0.1)
+    if leaf == "bias":
+        return _randn(rng, shape, 0.05)
+    if leaf == "weight":
+        if key == "g_s.final.weight":  # ConvTranspose2d (in, out, kh, kw): fan-in = in
+            return _randn(rng, shape, 1.0 / np.sqrt(shape[0]))
+        fan_in = int(np.prod(shape[1:]))
+        gain = 1.0
+        if key.endswith(("attn.proj.weight", "mlp.fc2.weight")):
+            gain = 0.5
+        if key == "quant_conv.weight":
+            gain = 1.5
+        if key == "h_a.quan_mlp.fc2.weight":
+            gain = 6.0
+        if key == "h_s.final.weight":
+            gain = 2.0
+        return _randn(rng, shape, gain / np.sqrt(fan_in))
+    return None
+
+
+@torch.no_grad()
+def fill_state_dict(shapes, seed=0, device="cpu"):
+    """shapes: {key: shape}. Returns {key: tensor} for every synthesised key."""
+    out = {}
+    for k, shp in shapes.items():
+        t = synth_tensor(k, shp, seed)
+        if t is not None:
+            out[k] = t.to(torch.float32).to(device)
+    return out
+
+
+def synth_frame(channels, seed, H=721, W=1440, kind="normal"):
+    """A synthetic normalised ERA5 snapshot (C, 721, 1440) fp32: N(0,1) like
+    normalised ERA5, or uniform [0,1) (README proxy input)."""
+    g = torch.Generator().manual_seed(int(seed))
+    if kind == "uniform":
+        return torch.rand((channels, H, W), generator=g, dtype=torch.float32)
+    return torch.randn((channels, H, W), generator=g, dtype=torch.float32)

@@ -1,0 +1,178 @@
+/* cra5_amd - MI355X (gfx950) native VAEformer encode/decode path: C ABI.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes
+ * only; no torch / pybind types.  Every function returns 0 on success; device
+ * launchers return the hipError_t of the launch (as int) otherwise, host functions
+ * a negative cra5 status.  No function allocates device memory; the caller owns all
+ * buffers and passes the hipStream_t to launch on (as void*).
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference
+ * tree taohan10200/CRA5):
+ *   - FFI #1 `compressai.ans`  cra5/models/compressai/cpp_exts/rans/rans_interface.cpp:361-381
+ *   - FFI #2 `compressai._CXX` cra5/models/compressai/cpp_exts/ops/ops.cpp:111-118
+ *   - the ATen op sites of the hot path (the reference has no device kernels of its
+ *     own): cra5/models/vaeformer/vit_nlc.py and
+ *     cra5/models/compressai/entropy_models/entropy_models.py, cited per function.
+ */
+#ifndef CRA5_AMD_H
+#define CRA5_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (host functions) ------------------------------------------- */
+#define CRA5_OK 0
+#define CRA5_ERR_ALLOC (-1)
+#define CRA5_ERR_INDEX (-2)     /* cdf index out of range                         */
+#define CRA5_ERR_PMF_DOMAIN (-3)/* negative / non-finite pmf entry (ops.cpp:46-52) */
+#define CRA5_ERR_PMF_ZERO (-4)  /* all-zero pmf (ops.cpp:60-64)                    */
+#define CRA5_ERR_PMF_STEAL (-5) /* no bin can donate frequency                     */
+#define CRA5_ERR_STREAM (-6)    /* truncated / corrupt rANS stream                 */
+#define CRA5_ERR_ARG (-7)
+
+int cra5_abi_version(void);
+
+/* ============================ host: entropy coding ============================ */
+
+/* RansEncoder.encode_with_indexes (rans_interface.cpp:202-213 -> :108-200).
+ * `cdfs` is a dense int32 matrix [n_cdfs][cdf_stride] (the `_quantized_cdf`
+ * buffer), `cdf_sizes` = `_cdf_length`, `offsets` = `_offset`.  The stream
+ * (little-endian 32-bit words) is malloc'ed into *out; release with cra5_free.
+ * Thread-safe: no global state, so many frames can be coded concurrently. */
+int cra5_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, size_t n,
+                                  const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                                  const int32_t *cdf_sizes, const int32_t *offsets,
+                                  uint8_t **out, size_t *out_len);
+
+/* RansDecoder.decode_with_indexes (rans_interface.cpp:215-284). `out` has n slots.
+ * Unlike the reference (which reads past the end of a corrupt stream) a truncated
+ * stream returns CRA5_ERR_STREAM. */
+int cra5_rans_decode_with_indexes(const uint8_t *encoded, size_t len, const int32_t *indexes,
+                                  size_t n, const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                                  const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out);
+
+/* Code `n_streams` independent streams on a pool of `n_threads` host threads
+ * (frames are independent units: entropy_models.py:263-272). Arrays of per-stream
+ * pointers; tables may be shared between streams. rc[i] receives each status. */
+int cra5_rans_encode_batch(int n_streams, const int32_t *const *symbols,
+                           const int32_t *const *indexes, const size_t *n,
+                           const int32_t *const *cdfs, const int *n_cdfs, const int *cdf_stride,
+                           const int32_t *const *cdf_sizes, const int32_t *const *offsets,
+                           uint8_t **out, size_t *out_len, int *rc, int n_threads);
+int cra5_rans_decode_batch(int n_streams, const uint8_t *const *encoded, const size_t *len,
+                           const int32_t *const *indexes, const size_t *n,
+                           const int32_t *const *cdfs, const int *n_cdfs, const int *cdf_stride,
+                           const int32_t *const *cdf_sizes, const int32_t *const *offsets,
+                           int32_t *const *out, int *rc, int n_threads);
+
+void cra5_free(void *p);
+
+/* pmf_to_quantized_cdf (ops.cpp:40-108). cdf has n+1 slots. */
+int cra5_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf);
+
+/* ============================ device: dense projections ======================= */
+
+/* C[M,N] = epilogue( A[M,K] . W[N,K]^T ), fp32 in / fp32 MFMA accumulate
+ * (v_mfma_f32_32x32x2_f32).  Replaces every nn.Linear / 1x1 Conv2d / im2col'ed
+ * Conv2d / ConvTranspose2d GEMM on the path (vit_nlc.py:57-59,96,111,216-217,302,
+ * 629-632,741; vaeformer.py:154-155).
+ *   flags: CRA5_EPI_BIAS  -> + bias[n]
+ *          CRA5_EPI_GELU  -> exact-erf GELU after bias (nn.GELU(), vit_nlc.py:52-69)
+ *          CRA5_EPI_RES   -> + res[m*ldr + n] (residual stream / pos_embed; res may
+ *                            alias C)
+ * Requirements: K % 4 == 0, lda % 4 == 0, ldw % 4 == 0, 16-byte aligned A, W. */
+#define CRA5_EPI_BIAS 1
+#define CRA5_EPI_GELU 2
+#define CRA5_EPI_RES 4
+int cra5_gemm_nt_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc,
+                     const float *bias, const float *res, int ldr, int M, int N, int K,
+                     int flags, void *stream);
+
+/* LayerNorm over the last dim (eps inside the sqrt), one row per wavefront
+ * (partial(nn.LayerNorm, eps=1e-6): vit_nlc.py:266,278,381,626). D % 4 == 0, D <= 2048. */
+int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float *beta, float *y,
+                       int ldy, int rows, int D, float eps, void *stream);
+
+/* ============================ device: attention =============================== */
+
+/* Streaming-softmax multi-head attention over windows of a (H, W) token grid, fp32
+ * MFMA.  qkv: [H*W][3*C] rows = [q | k | v], each [heads][hd].  Windows are (wh, ww)
+ * tiles of the grid zero-padded bottom/right to multiples of (wh, ww); a padded token
+ * carries q = k = v = pad_row (the qkv bias) and attention is UNMASKED over the 576
+ * tokens of a window (vit_nlc.py:219-258); wh = H, ww = W gives the global attention
+ * of vit_nlc.py:94-112.  out: [H*W][C] (pre-projection), padded queries dropped.
+ * hd must be 64 or 72. */
+int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out, int C,
+                              int heads, int H, int W, int wh, int ww, float scale,
+                              void *stream);
+
+/* ============================ device: layout / conv edges ===================== */
+
+/* Patch gather for a strided Conv2d as GEMM (vit_nlc.py:302-308), fused with the API's
+ * normalisation (x - mean[c]) / std[c] (cra5_api.py:264-266) when mean != NULL.
+ * x: [C][H][W]; cols: [Hp*Wp][ldk], column (c*kh + i)*kw + j; columns >= C*kh*kw are
+ * left untouched (keep them zero). */
+int cra5_im2col_f32(const float *x, const float *mean, const float *std, float *cols, int C,
+                    int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk,
+                    void *stream);
+
+/* Overlap-add scatter of a ConvTranspose2d computed as GEMM (vit_nlc.py:628-630,
+ * 666-669), fused with de-normalisation x*std[c] + mean[c] (cra5_api.py:268-271) when
+ * mean != NULL.  cols: [Hp*Wp][ldn], column (c*kh + i)*kw + j;  x: [C][H][W] with
+ * H = (Hp-1)*sh + kh, W = (Wp-1)*sw + kw. */
+int cra5_col2im_f32(const float *cols, const float *mean, const float *std, float *x, int C,
+                    int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp, int ldn,
+                    void *stream);
+
+/* out[c][r] = in[r][c] (token-major <-> NCHW plumbing, vit_nlc.py:484, 684). */
+int cra5_transpose_f32(const float *in, int ld_in, float *out, int ld_out, int rows, int cols,
+                       void *stream);
+
+/* 'b h w (p1 p2 c) -> b c (h p1) (w p2)' (vit_nlc.py:672-679): lin [Hz*Wz][p1*p2*Cout]
+ * -> out [Cout][Hz*p1][Wz*p2]. */
+int cra5_pixel_shuffle_f32(const float *lin, float *out, int Hz, int Wz, int p1, int p2,
+                           int Cout, void *stream);
+
+/* ============================ device: entropy models ========================== */
+
+/* GaussianConditional, eval mode (entropy_models.py:645-685, 155-201):
+ *   s = max(scale, bound);  idx = (n_table-1) - #{t in table[0:n_table-1] : s <= t}
+ *   sym = (int)rintf(y - mean);  y_hat = sym + mean
+ *   lik = max(Phi((.5-|y_hat-mean|)/s) - Phi((-.5-|y_hat-mean|)/s), lik_bound)
+ * Any output pointer may be NULL.  If y == NULL and sym_in != NULL the kernel
+ * de-quantises instead: y_hat = sym_in + mean (decode side, :192-201). */
+int cra5_gaussian_conditional_f32(const float *y, const int32_t *sym_in, const float *scales,
+                                  const float *means, const float *scale_table, int n_table,
+                                  float scale_bound, float lik_bound, int32_t *idx, int32_t *sym,
+                                  float *y_hat, float *lik, size_t n, void *stream);
+
+/* EntropyBottleneck, eval mode (entropy_models.py:434-510, 529-542): z is [C][n_per_ch];
+ *   sym = (int)rintf(z - median[c]);  z_hat = sym + median[c]
+ *   lik = max(sigmoid(logits(z_hat+.5)) - sigmoid(logits(z_hat-.5)), lik_bound)
+ * params: per channel 58 floats: softplus(M0)[3] b0[3] tanh(f0)[3] | softplus(M1)[9] b1[3]
+ * tanh(f1)[3] | M2.. | M3.. | softplus(M4)[3] b4[1]  (prepared on the host).
+ * If z == NULL and sym_in != NULL: z_hat = sym_in + median (decode side). */
+int cra5_entropy_bottleneck_f32(const float *z, const int32_t *sym_in, const float *medians,
+                                const float *params, float lik_bound, int32_t *sym, float *z_hat,
+                                float *lik, int C, int n_per_ch, void *stream);
+
+/* GDN / IGDN (cra5/models/compressai/layers/gdn.py:76-92): x, y: [B][C][HW];
+ * y = x * rsqrt(beta[i] + sum_j gamma[i][j] x_j^2)   (inverse: * sqrt).
+ * beta / gamma are the re-parametrised (effective) values. */
+int cra5_gdn_f32(const float *x, const float *beta, const float *gamma, float *y, int B, int C,
+                 int HW, int inverse, void *stream);
+
+/* Device-side timing helpers for bench.py (HIP events on the launch stream). */
+int cra5_event_create(void **ev);
+int cra5_event_record(void *ev, void *stream);
+int cra5_event_elapsed_ms(void *start, void *stop, float *ms);
+int cra5_event_destroy(void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRA5_AMD_H */

@@ -1,0 +1,259 @@
+"""Golden-vector generator (BUILD CONTAINER ONLY - needs /root/reference).
+
+Imports the reference's own Python through oracle/ref_shim.py, loads the
+deterministic synthetic weights of cra5_amd/synth.py into the reference model and
+dumps small input/output fixtures (data only) next to this script:
+
+  pmf_cdf.json          outputs of the reference's ops.cpp (compiled as oracle/_ref/_CXX)
+  state_keys.json       state-dict key -> shape of the 268 model and the thin model
+  tables_default.npz    GaussianConditional.update() tables for get_scale_table() and
+                        EntropyBottleneck.update() tables at the synthetic EB params
+  ops_small.npz         per-op outputs (window attention x3 incl. padding, global
+                        attention hd=72, block, patch-embed, un-embed, hyper un-embed)
+  thin_e2e.npz          full-spatial thin model: every stage of encode / latent side /
+                        decode, sub-sampled, + rANS strings
+  full268.npz           (--stage full; ~3 min, ~18 GB RAM) the real 268 architecture
+
+Usage:  python tests/golden/make_golden.py --stage small thin [full]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+from cra5.models.vaeformer.vaeformer import VAEformer  # noqa: E402  (reference)
+from cra5.models.vaeformer import vit_nlc  # noqa: E402  (reference)
+from cra5.models.compressai.entropy_models import GaussianConditional  # noqa: E402
+from cra5.models.compressai.models.base import get_scale_table  # noqa: E402
+from cra5.models.compressai.layers.gdn import GDN  # noqa: E402
+import cra5.models.compressai._CXX as REF_CXX  # noqa: E402
+
+from cra5_amd import synth  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+THIN_DD_KW = dict(z_dim=None, learnable_pos=True, window=True, window_size=[(24, 24), (12, 48), (48, 12)],
+                  interval=4, drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                  test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=True,
+                  img_size=(721, 1440), embed_dim=128, depth=8, num_heads=2)
+THIN_PRIOR_KW = dict(z_dim=16, embed_dim=144, depth=4, num_heads=2, interval=1, learnable_pos=True,
+                     window=False, drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                     test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=False,
+                     img_size=(72, 144))
+
+
+def build_thin():
+    return VAEformer(0, embed_dim=16, z_channels=16, y_channels=128, sample_posterior=False,
+                     frozen_encoder=False, lower_dim=True,
+                     ddconfig=dict(arch='vit_base', patch_size=(11, 10), patch_stride=(10, 10), in_chans=8,
+                                   out_chans=8, pretrained_model='', kwargs=dict(THIN_DD_KW)),
+                     priorconfig=dict(patch_size=(4, 4), in_chans=16, out_chans=16, pretrained_model='',
+                                      kwargs=dict(THIN_PRIOR_KW))).eval()
+
+
+def load_synth(net, seed):
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.fill_state_dict(shapes, seed)
+    missing, unexpected = torch.nn.Module.load_state_dict(net, sd, strict=False)
+    assert not unexpected, unexpected
+    net.update(force=True)
+    return shapes
+
+
+def sub(t, step):
+    return t.detach().reshape(-1)[::step].clone().numpy()
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), (t * t).sum().item(), t.abs().max().item()], dtype=np.float64)
+
+
+def stage_small():
+    # ---- pmf -> cdf ---------------------------------------------------------
+    rng = np.random.default_rng(1234)
+    cases = []
+    for t in range(40):
+        n = int(rng.integers(1, 64))
+        p = rng.random(n).astype(np.float32) ** int(rng.integers(1, 9))
+        p /= p.sum()
+        if t % 4 == 0 and n > 3:
+            p[rng.integers(0, n, size=n // 2)] = 0.0
+        if t % 7 == 0:
+            p = (p * 0.37).astype(np.float32)  # un-normalised
+        if float(p.sum()) == 0.0:
+            p[0] = 1.0
+        cases.append(dict(pmf=[float(v) for v in p], precision=16,
+                          cdf=[int(v) for v in REF_CXX.pmf_to_quantized_cdf([float(v) for v in p], 16)]))
+    cases.append(dict(pmf=[1.0], precision=16, cdf=[int(v) for v in REF_CXX.pmf_to_quantized_cdf([1.0], 16)]))
+    tiny = [1e-9] * 30 + [1.0]
+    cases.append(dict(pmf=tiny, precision=16, cdf=[int(v) for v in REF_CXX.pmf_to_quantized_cdf(tiny, 16)]))
+    errs = []
+    for bad in ([-0.1, 0.5], [float("nan"), 1.0], [float("inf")], [0.0, 0.0]):
+        try:
+            REF_CXX.pmf_to_quantized_cdf(bad, 16)
+            errs.append(dict(pmf=[repr(v) for v in bad], raises=False))
+        except Exception as e:  # noqa: BLE001
+            errs.append(dict(pmf=[repr(v) for v in bad], raises=True, type=type(e).__name__))
+    json.dump(dict(cases=cases, errors=errs), open(os.path.join(HERE, "pmf_cdf.json"), "w"))
+
+    # ---- state-dict layouts ---------------------------------------------------
+    thin = build_thin()
+    thin_shapes = {k: list(v.shape) for k, v in thin.state_dict().items()}
+    big = VAEformer(268)
+    big_shapes = {k: list(v.shape) for k, v in big.state_dict().items()}
+    del big
+    json.dump(dict(thin=thin_shapes, v268=big_shapes), open(os.path.join(HERE, "state_keys.json"), "w"))
+
+    # ---- default tables -------------------------------------------------------
+    gc = GaussianConditional(None)
+    gc.update_scale_table(get_scale_table(), force=True)
+    load_synth(thin, seed=7)
+    eb = thin.entropy_bottleneck
+    np.savez_compressed(os.path.join(HERE, "tables_default.npz"),
+                        scale_table=gc.scale_table.numpy(), gc_cdf=gc._quantized_cdf.numpy(),
+                        gc_len=gc._cdf_length.numpy(), gc_off=gc._offset.numpy(),
+                        eb_cdf=eb._quantized_cdf.numpy(), eb_len=eb._cdf_length.numpy(),
+                        eb_off=eb._offset.numpy())
+
+    # ---- per-op fixtures ------------------------------------------------------
+    out = {}
+    vit_nlc.COMPAT = False
+    H, W, C, heads = 72, 144, 128, 2
+    g = torch.Generator().manual_seed(11)
+    xtok = torch.randn(1, H * W, C, generator=g)
+    out["tok_in_step"] = np.array([1])
+    for name, ws in (("w24", (24, 24)), ("w12x48", (12, 48)), ("w48x12", (48, 12))):
+        m = vit_nlc.WindowAttention(C, ws, heads, qkv_bias=True).eval()
+        shapes = {f"attn.{k}": tuple(v.shape) for k, v in m.state_dict().items()}
+        sd = synth.fill_state_dict(shapes, seed=21)
+        m.load_state_dict({k[5:]: v for k, v in sd.items()})
+        out[f"winattn_{name}"] = sub(m(xtok, H, W), 61)
+    m = vit_nlc.Attention(144, num_heads=2, qkv_bias=True).eval()
+    sd = synth.fill_state_dict({f"attn.{k}": tuple(v.shape) for k, v in m.state_dict().items()}, seed=22)
+    m.load_state_dict({k[5:]: v for k, v in sd.items()})
+    x648 = torch.randn(1, 648, 144, generator=g)
+    out["globattn_hd72"] = sub(m(x648, 18, 36), 7)
+    m = vit_nlc.Attention(C, num_heads=heads, qkv_bias=True).eval()
+    sd = synth.fill_state_dict({f"attn.{k}": tuple(v.shape) for k, v in m.state_dict().items()}, seed=23)
+    m.load_state_dict({k[5:]: v for k, v in sd.items()})
+    out["globattn_hd64"] = sub(m(xtok, H, W), 61)
+    for name, ws, win in (("blk_w48x12", (48, 12), True), ("blk_glob", (72, 144), False)):
+        m = vit_nlc.Block(C, heads, mlp_ratio=4, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6),
+                          window_size=ws, window=win).eval()
+        sd = synth.fill_state_dict({f"blocks.0.{k}": tuple(v.shape) for k, v in m.state_dict().items()}, seed=24)
+        m.load_state_dict({k[9:]: v for k, v in sd.items()})
+        out[name] = sub(m(xtok, H, W), 61)
+    # GDN / IGDN
+    for inv in (False, True):
+        m = GDN(12, inverse=inv).eval()
+        gg = torch.Generator().manual_seed(31)
+        m.beta.data = m.beta.data + 0.3 * torch.rand(12, generator=gg)
+        m.gamma.data = m.gamma.data + 0.05 * torch.rand(12, 12, generator=gg)
+        xg = torch.randn(2, 12, 9, 7, generator=gg)
+        out[f"gdn_inv{int(inv)}_beta"] = m.beta.data.numpy()
+        out[f"gdn_inv{int(inv)}_gamma"] = m.gamma.data.numpy()
+        out[f"gdn_inv{int(inv)}_x"] = xg.numpy()
+        out[f"gdn_inv{int(inv)}_y"] = m(xg).numpy()
+    np.savez_compressed(os.path.join(HERE, "ops_small.npz"), **out)
+    print("small done")
+
+
+def run_e2e(net, x, yhat_synth, step_lat, step_img, tag):
+    """All stages of the reference path on `x`; returns dict of sub-sampled arrays."""
+    o = {}
+    t0 = time.time()
+    moments = net.quant_conv(net.g_a(x))
+    y = moments[:, : moments.shape[1] // 2]
+    print(tag, "g_a", time.time() - t0)
+    o["y_sub"], o["y_stats"] = sub(y, step_lat), stats(y)
+    z = net.h_a(y)
+    o["z"] = z.numpy().astype(np.float32) if z.numel() < 20000 else sub(z, 13)
+    o["z_stats"] = stats(z)
+    z_hat, z_lik = net.entropy_bottleneck(z)
+    o["z_lik_sub"] = sub(z_lik, 13)
+    z_strings = net.entropy_bottleneck.compress(z)
+    z_hat2 = net.entropy_bottleneck.decompress(z_strings, z.size()[-2:])
+    assert torch.equal(z_hat, z_hat2)
+    o["z_sym"] = net.entropy_bottleneck.quantize(
+        z, "symbols", net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)).numpy().astype(np.int32)
+    if o["z_sym"].size > 20000:
+        o["z_sym_hist"] = np.bincount((o["z_sym"].reshape(-1) + 64).clip(0, 128), minlength=129)
+        o["z_sym"] = o["z_sym"].reshape(-1)[::13]
+    params = net.h_s(z_hat)
+    scales, means = params.chunk(2, 1)
+    o["scales_sub"], o["means_sub"] = sub(scales, step_lat), sub(means, step_lat)
+    o["scales_stats"], o["means_stats"] = stats(scales), stats(means)
+    idx = net.gaussian_conditional.build_indexes(scales)
+    o["idx_sub"] = sub(idx, step_lat).astype(np.int32)
+    o["idx_hist"] = np.bincount(idx.reshape(-1).numpy(), minlength=64)
+    y_hat, y_lik = net.gaussian_conditional(y, scales, means=means)
+    o["y_lik_sub"] = sub(y_lik, step_lat)
+    sym = net.gaussian_conditional.quantize(y, "symbols", means)
+    o["sym_sub"] = sub(sym, step_lat).astype(np.int32)
+    o["sym_hist"] = np.bincount((sym.reshape(-1).numpy() + 256).clip(0, 512), minlength=513)
+    o["y_hat_sub"] = sub(y_hat, step_lat)
+    o["bits_y"] = np.array([float((-torch.log2(y_lik)).sum())])
+    o["bits_z"] = np.array([float((-torch.log2(z_lik)).sum())])
+    t0 = time.time()
+    y_strings = net.gaussian_conditional.compress(y, idx, means=means)
+    print(tag, "rans y", time.time() - t0, len(y_strings[0]))
+    o["y_string_len"] = np.array([len(y_strings[0])])
+    o["z_string"] = np.frombuffer(z_strings[0], dtype=np.uint8)
+    if len(y_strings[0]) < 400000:
+        o["y_string"] = np.frombuffer(y_strings[0], dtype=np.uint8)
+    import hashlib
+    o["y_string_sha256"] = np.frombuffer(hashlib.sha256(y_strings[0]).digest(), dtype=np.uint8)
+    # decoder given a synthetic, regenerable y_hat (independent of round() flips)
+    t0 = time.time()
+    x_hat = net.decode_latent(yhat_synth)
+    print(tag, "g_s", time.time() - t0)
+    o["xhat_sub"], o["xhat_stats"] = sub(x_hat, step_img), stats(x_hat)
+    # overlap rows (10, 20, ...) get two contributions: keep one full overlap row
+    o["xhat_row10_c0"] = x_hat[0, 0, 10].numpy()
+    o["xhat_row720_c0"] = x_hat[0, 0, 720].numpy()
+    return o
+
+
+def synth_yhat(latent, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.round(2.0 * torch.randn(1, latent, 72, 144, generator=g)) + torch.randn(1, latent, 72, 144, generator=g)
+
+
+def stage_thin():
+    net = build_thin()
+    load_synth(net, seed=7)
+    x = synth.synth_frame(8, seed=2).unsqueeze(0)
+    o = run_e2e(net, x, synth_yhat(16, 5), step_lat=37, step_img=1009, tag="thin")
+    np.savez_compressed(os.path.join(HERE, "thin_e2e.npz"), **o)
+    print("thin done")
+
+
+def stage_full():
+    net = VAEformer(268).eval()
+    load_synth(net, seed=7)
+    x = synth.synth_frame(268, seed=2).unsqueeze(0)
+    o = run_e2e(net, x, synth_yhat(256, 5), step_lat=499, step_img=99991, tag="full")
+    np.savez_compressed(os.path.join(HERE, "full268.npz"), **o)
+    print("full done")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stage", nargs="+", default=["small", "thin"])
+    a = ap.parse_args()
+    for s in a.stage:
+        dict(small=stage_small, thin=stage_thin, full=stage_full)[s]()

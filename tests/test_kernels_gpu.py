@@ -1,0 +1,213 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI
+(cra5_amd.ops -> libcra5_amd.so), against the CPU oracle (oracle/torch_ref.py) on the
+same seeded inputs.  Floating point: tolerances are written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+from cra5_amd import ops, synth
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rmse(a, b):
+    return float(torch.sqrt(torch.mean((a.double().cpu() - b.double().cpu()) ** 2)))
+
+
+def relerr(a, b):
+    b = b.double().cpu()
+    return rmse(a, b) / max(float(torch.sqrt(torch.mean(b ** 2))), 1e-30)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 64), (648, 360, 360), (1000, 1080, 360),
+                                   (10368, 1024, 1024), (333, 77, 52), (2048, 4096, 1024), (70, 8192, 360)])
+@pytest.mark.parametrize("epi", ["none", "bias", "gelu", "res", "gelu_res"])
+def test_gemm_nt(dev, M, N, K, epi):
+    if M * N * K > 2e9 and epi not in ("none", "gelu_res"):
+        pytest.skip("big shape: two epilogues are enough")
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().t()
+    if epi != "none":
+        ref = ref + b.double()
+    if "gelu" in epi:
+        ref = torch.nn.functional.gelu(ref)
+    if "res" in epi:
+        ref = ref + r.double()
+    out = ops.gemm_nt(a.to(dev), w.to(dev), bias=b.to(dev) if epi != "none" else None,
+                      res=r.to(dev) if "res" in epi else None, gelu="gelu" in epi)
+    torch.cuda.synchronize()
+    # fp32 fmaf chain over K <= 1024 vs fp64: ~1e-7 relative (guide: 0.75-1.5e-7 * sum|ab|)
+    assert relerr(out, ref) < 2e-6
+
+
+def test_gemm_asymmetric_layout(dev):
+    """A = I with an asymmetric W catches row/col swaps of the MFMA C layout."""
+    n = 128
+    a = torch.eye(n)
+    w = torch.arange(n * n, dtype=torch.float32).reshape(n, n)  # W[n][k]
+    out = ops.gemm_nt(a.to(dev), w.to(dev))
+    assert torch.equal(out.cpu(), w.t())
+
+
+def test_gemm_strided_and_inplace_residual(dev):
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(300, 512, generator=g).to(dev)
+    a = big[:, 128:384]           # lda = 512, K = 256
+    w = torch.randn(96, 256, generator=g).to(dev)
+    x = torch.randn(300, 96, generator=g).to(dev)
+    ref = x.double().cpu() + a.double().cpu() @ w.double().cpu().t()
+    ops.gemm_nt(a, w, res=x, out=x)   # in-place residual update
+    assert relerr(x, ref) < 2e-6
+
+
+@pytest.mark.parametrize("rows,D", [(10368, 1024), (648, 360), (100, 128), (7, 144), (33, 2048)])
+def test_layernorm(dev, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 3 + 1.5
+    ga = torch.randn(D, generator=g)
+    be = torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), ga.double(), be.double(), 1e-6)
+    out = ops.layernorm(x.to(dev), ga.to(dev), be.to(dev), 1e-6)
+    assert rmse(out, ref) < 1e-6  # fp32 rounding of O(1) values
+
+
+def _attn_gpu(x, sd, pre, heads, H, W, ws, dev):
+    qkv = ops.gemm_nt(x.to(dev), sd[pre + ".qkv.weight"].to(dev), bias=sd[pre + ".qkv.bias"].to(dev))
+    wh, ww = ws if ws is not None else (H, W)
+    o = ops.window_attention(qkv, sd[pre + ".qkv.bias"].to(dev), heads, H, W, wh, ww)
+    return ops.gemm_nt(o, sd[pre + ".proj.weight"].to(dev), bias=sd[pre + ".proj.bias"].to(dev))
+
+
+@pytest.mark.parametrize("ws", [(24, 24), (12, 48), (48, 12), None])
+def test_window_attention_hd64(dev, ws):
+    H, W, C, heads = 72, 144, 128, 2
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, H * W, C, generator=g)
+    shapes = {"attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,), "attn.proj.weight": (C, C),
+              "attn.proj.bias": (C,)}
+    sd = synth.fill_state_dict(shapes, seed=21)
+    sd["attn.qkv.weight"] *= 3.0  # sharper softmax
+    xd = {k: v.double() for k, v in sd.items()}
+    if ws is None:
+        ref = R.attention_global(x.double(), xd, "attn", heads)
+    else:
+        ref = R.attention_window(x.double(), xd, "attn", heads, H, W, ws)
+    out = _attn_gpu(x[0], sd, "attn", heads, H, W, ws, dev)
+    # tolerance: fp32 matmuls + fast exp; outputs are O(0.3)
+    assert rmse(out, ref[0]) < 2e-6, rmse(out, ref[0])
+
+
+def test_global_attention_hd72_ragged(dev):
+    """648 tokens (not a multiple of the 32-key tile) and head dim 72: hyper-prior shape."""
+    H, W, C, heads = 18, 36, 144, 2
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(1, H * W, C, generator=g)
+    shapes = {"attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,), "attn.proj.weight": (C, C),
+              "attn.proj.bias": (C,)}
+    sd = synth.fill_state_dict(shapes, seed=22)
+    sd["attn.qkv.weight"] *= 3.0
+    ref = R.attention_global(x.double(), {k: v.double() for k, v in sd.items()}, "attn", heads)
+    out = _attn_gpu(x[0], sd, "attn", heads, H, W, None, dev)
+    assert rmse(out, ref[0]) < 2e-6
+
+
+def test_attention_softmax_spike(dev):
+    """One key dominates late in the sequence: forces the online-softmax rescale path."""
+    H, W, C, heads = 8, 72, 64, 1
+    N = H * W
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(N, 3 * C, generator=g)
+    qkv[:, C:2 * C] *= 0.1
+    qkv[500, C:2 * C] = qkv[17, :C] * 4.0   # key 500 matches query 17 strongly
+    q, k, v = qkv[:, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
+    ref = torch.softmax((q * C ** -0.5) @ k.t(), -1) @ v
+    out = ops.window_attention(qkv.to(dev), torch.zeros(3 * C, device=dev), heads, H, W, H, W)
+    assert rmse(out, ref) < 2e-6
+
+
+def test_im2col_col2im(dev):
+    g = torch.Generator().manual_seed(4)
+    C, H, W = 5, 721, 1440
+    x = torch.randn(C, H, W, generator=g)
+    mean = torch.randn(C, generator=g)
+    std = torch.rand(C, generator=g) + 0.5
+    cols = ops.im2col(x.to(dev), 11, 10, 10, 10, ldk=576, mean=mean.to(dev), std=std.to(dev))
+    xn = (x - mean[:, None, None]) / std[:, None, None]
+    ref = torch.nn.functional.unfold(xn[None], (11, 10), stride=(10, 10))[0].t()  # [tokens, C*110]
+    assert torch.equal(cols[:, :550].cpu(), ref)            # bit-exact: same IEEE ops
+    assert torch.count_nonzero(cols[:, 550:]) == 0
+    # overlap-add back (ConvTranspose2d with identity "weights")
+    back = ops.col2im(cols[:, :550], C, 11, 10, 10, 10, 72, 144)
+    ref_back = torch.nn.functional.fold(ref.t()[None], (H, W), (11, 10), stride=(10, 10))[0]
+    assert rmse(back, ref_back) < 1e-7
+    den = ops.col2im(cols[:, :550], C, 11, 10, 10, 10, 72, 144, mean=mean.to(dev), std=std.to(dev))
+    assert rmse(den, ref_back * std[:, None, None] + mean[:, None, None]) < 1e-6
+
+
+def test_transpose_pixel_shuffle(dev):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(10368, 256, generator=g)
+    assert torch.equal(ops.transpose(x.to(dev)).cpu(), x.t())
+    x = torch.randn(77, 45, generator=g)
+    assert torch.equal(ops.transpose(x.to(dev)).cpu(), x.t())
+    lin = torch.randn(18 * 36, 4 * 4 * 32, generator=g)
+    from einops import rearrange
+    ref = rearrange(lin.reshape(1, 18, 36, -1), "b h w (p1 p2 c) -> b c (h p1) (w p2)", p1=4, p2=4)[0]
+    assert torch.equal(ops.pixel_shuffle(lin.to(dev), 18, 36, 4, 4).cpu(), ref)
+
+
+def test_gaussian_conditional(dev):
+    g = torch.Generator().manual_seed(8)
+    n = (1, 16, 72, 144)
+    y = torch.randn(n, generator=g) * 3
+    means = torch.randn(n, generator=g)
+    scales = torch.randn(n, generator=g).abs() * 4 - 0.5
+    table = R.get_scale_table()
+    scales.view(-1)[:64] = table            # exact table hits (<= comparison edge)
+    scales.view(-1)[64:128] = table * (1 + 1e-7)
+    o = ops.gaussian_conditional(scales.to(dev), means.to(dev), table.to(dev), y=y.to(dev),
+                                 want=("idx", "sym", "y_hat", "lik"))
+    assert torch.equal(o["idx"].cpu(), R.gc_build_indexes(scales, table))       # integers: bit-exact
+    assert torch.equal(o["sym"].cpu(), R.gc_symbols(y, means))
+    y_hat, lik = R.gc_forward(y, scales, means)
+    assert torch.equal(o["y_hat"].cpu(), y_hat)
+    assert float((o["lik"].cpu() - lik).abs().max()) < 2e-7                       # erfc implementation noise
+    d = ops.gaussian_conditional(scales.to(dev), means.to(dev), table.to(dev), sym_in=o["sym"], want=("y_hat",))
+    assert torch.equal(d["y_hat"].cpu(), y_hat)
+
+
+def test_entropy_bottleneck(dev):
+    from cra5_amd.entropy import eb_pack_params
+    C = 16
+    shapes = {f"entropy_bottleneck._matrix{i}": s for i, s in enumerate([(C, 3, 1), (C, 3, 3), (C, 3, 3), (C, 3, 3), (C, 1, 3)])}
+    shapes.update({f"entropy_bottleneck._bias{i}": s for i, s in enumerate([(C, 3, 1)] * 4 + [(C, 1, 1)])})
+    shapes.update({f"entropy_bottleneck._factor{i}": (C, 3, 1) for i in range(4)})
+    shapes["entropy_bottleneck.quantiles"] = (C, 1, 3)
+    sd = synth.fill_state_dict(shapes, seed=9)
+    g = torch.Generator().manual_seed(10)
+    z = torch.randn(1, C, 18, 36, generator=g) * 5
+    z_hat, lik = R.eb_forward(z, sd)
+    sym = R.eb_symbols(z, sd)
+    med = R.eb_medians(sd)
+    o = ops.entropy_bottleneck(med.to(dev), eb_pack_params(sd).to(dev), z=z[0].reshape(C, -1).contiguous().to(dev),
+                               want=("sym", "z_hat", "lik"))
+    assert torch.equal(o["sym"].cpu().reshape(sym.shape[1:]), sym[0])
+    assert torch.equal(o["z_hat"].cpu().reshape(z_hat.shape[1:]), z_hat[0])
+    assert float((o["lik"].cpu().reshape(lik.shape[1:]) - lik[0]).abs().max()) < 5e-7
+
+
+def test_gdn_golden(dev, golden_dir):
+    d = np.load(f"{golden_dir}/ops_small.npz")
+    for inv in (0, 1):
+        x = torch.from_numpy(d[f"gdn_inv{inv}_x"])
+        beta_p, gamma_p = torch.from_numpy(d[f"gdn_inv{inv}_beta"]), torch.from_numpy(d[f"gdn_inv{inv}_gamma"])
+        ped = (2 ** -18) ** 2
+        beta = torch.clamp(beta_p, min=(1e-6 + ped) ** 0.5) ** 2 - ped
+        gamma = torch.clamp(gamma_p, min=ped ** 0.5) ** 2 - ped
+        y = ops.gdn(x.to(dev), beta.to(dev), gamma.contiguous().to(dev), inverse=bool(inv))
+        assert rmse(y, torch.from_numpy(d[f"gdn_inv{inv}_y"])) < 1e-6
