@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py - ERA5 frames/s (721x1440x268) encode+decode on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...)
+
+A "step" is one pass of the hot path over one synthetic frame on each rank:
+    x (268x721x1440 fp32, resident in HBM) -> g_a -> y -> h_a/EB/h_s/GC -> rANS .bin
+    -> rANS decode -> h_s -> y_hat -> g_s -> x_hat          (BASELINE.json configs[2])
+with deterministic synthetic weights of the real 404.7 M-parameter architecture (there
+is no network for the checkpoint / ERA5 samples).  Frames shard over ranks with no
+data-path collective (weak scaling: one frame per rank per step); the only exchange is
+the RCCL all-gather of per-frame bitstream stats after the timed region.
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus
+  "roofline":     achieved fp32 MFMA TFLOP/s of the dominant kernel (gemm_nt_f32), timed
+                  with HIP events on the launch stream over the timed region;
+  "cpu_baseline": the CPU oracle (oracle/torch_ref.py = restatement of the reference's
+                  math path + oracle C rANS) timed on this box's host cores on a bounded
+                  sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FLOP_PER_FRAME = 11.57e12      # encode 6.132 + decode 5.415 + hyper-prior
+
+
+def cpu_baseline(quality, n_threads):
+    """Bounded CPU sample of the same workload with the oracle (kind = "port")."""
+    from cra5_amd import synth
+    from oracle import cbind
+    from oracle import torch_ref as R
+    import numpy as np
+    torch.set_num_threads(n_threads)
+    cfg = R.cfg_268(quality)
+    D, heads = cfg["embed_dim"], cfg["num_heads"]
+    names = {}
+    for k, shp in (("g_a.patch_embed.proj.weight", (D, quality, 11, 10)), ("g_a.patch_embed.proj.bias", (D,)),
+                   ("g_a.pos_embed", (1, 10368, D))):
+        names[k] = shp
+    for b in (0, 3):
+        p = f"g_a.blocks.{b}"
+        names.update({f"{p}.norm1.weight": (D,), f"{p}.norm1.bias": (D,), f"{p}.attn.qkv.weight": (3 * D, D),
+                      f"{p}.attn.qkv.bias": (3 * D,), f"{p}.attn.proj.weight": (D, D), f"{p}.attn.proj.bias": (D,),
+                      f"{p}.norm2.weight": (D,), f"{p}.norm2.bias": (D,), f"{p}.mlp.fc1.weight": (4 * D, D),
+                      f"{p}.mlp.fc1.bias": (4 * D,), f"{p}.mlp.fc2.weight": (D, 4 * D), f"{p}.mlp.fc2.bias": (D,)})
+    sd = synth.fill_state_dict(names, seed=7)
+    x = synth.synth_frame(quality, seed=2).unsqueeze(0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        t = torch.nn.functional.conv2d(x, sd["g_a.patch_embed.proj.weight"], sd["g_a.patch_embed.proj.bias"],
+                                       stride=(10, 10)).flatten(2).transpose(1, 2) + sd["g_a.pos_embed"]
+        t1 = time.perf_counter()
+        t = R.block(t, sd, "g_a.blocks.0", heads, 72, 144, (24, 24))
+        t2 = time.perf_counter()
+        t = R.block(t, sd, "g_a.blocks.3", heads, 72, 144, None)
+        t3 = time.perf_counter()
+    # entropy coder on a full frame's worth of symbols (default GC tables, unit-scale data)
+    tb = R.gc_tables(R.get_scale_table(), cbind.pmf_to_cdf)
+    rng = np.random.default_rng(0)
+    n = 256 * 72 * 144
+    idx = rng.integers(0, 40, size=n).astype(np.int32)
+    sym = np.rint(rng.standard_normal(n) * 2).astype(np.int32)
+    t4 = time.perf_counter()
+    s = cbind.rans_encode(sym, idx, tb[0], tb[1], tb[2])
+    t5 = time.perf_counter()
+    d = cbind.rans_decode(s, idx, tb[0], tb[1], tb[2])
+    t6 = time.perf_counter()
+    assert np.array_equal(d.numpy(), sym)
+    t_pe, t_win, t_glob = t1 - t0, t2 - t1, t3 - t2
+    # 13 encoder + 12 decoder blocks = 18 windowed + 7 global; un-embed costs about one patch-embed
+    est = 2 * t_pe + 18 * t_win + 7 * t_glob + (t5 - t4) + (t6 - t5)
+    return {"value": 1.0 / est, "unit": "frames/s", "cores": n_threads, "kind": "port",
+            "sample": (f"oracle/torch_ref.py on {n_threads} host threads, quality={quality}, full 721x1440 frame: "
+                       f"patch-embed {t_pe:.2f}s + 1 windowed block {t_win:.2f}s + 1 global block (materialised "
+                       f"scores) {t_glob:.2f}s, + oracle C rANS encode {t5 - t4:.2f}s / decode {t6 - t5:.2f}s of "
+                       f"2.65M symbols; frame time extrapolated as 2*pe + 18*win + 7*glob + rANS = {est:.1f}s")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--quality", type=int, default=268)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from cra5_amd import dist as D
+    from cra5_amd import ops, synth
+    from cra5_amd.zoo import vaeformer_pretrained
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only product path")
+    rank, world, local = D.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    net = vaeformer_pretrained(quality=args.quality, pretrained=False)
+    synth.load_synthetic(net, seed=7)
+    net = net.to(dev)
+    C = args.quality
+    # two distinct frames per rank, resident in HBM before the timed region
+    frames = [synth.synth_frame(C, seed=1000 + 2 * rank + i).unsqueeze(0).to(dev) for i in range(2)]
+
+    def step(i):
+        x = frames[i % 2]
+        out = net.compress(x)
+        rec = net.decompress(out["strings"], out["z_shape"])
+        return out, rec["x_hat"]
+
+    for i in range(args.warmup):
+        step(i)
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    torch.cuda.synchronize()
+    D.barrier()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    rows = []
+    for i in range(args.steps):
+        out, x_hat = step(i)
+        rows.append(D.frame_stats(rank * args.steps + i, out["strings"]))
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    elapsed = D.max_over_ranks(elapsed, dev)
+    stats = D.gather_stats(rows, dev)  # RCCL all-gather of per-frame bitstream stats
+
+    total_frames = world * args.steps
+    fps = total_frames / elapsed
+    result = {
+        "metric": "ERA5 frames/s (721x1440x268) encode+decode",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"quality={C} single-frame full encode->bin->decode round trip per step "
+                               f"(BASELINE.json configs[2]); 1 frame/rank/step, frames sharded over ranks",
+                   "frame": [C, 721, 1440], "weights": "deterministic synthetic (cra5_amd/synth.py seed 7)",
+                   "parallelism": f"frame-sharded x{world}, weights replicated"},
+        "bytes_per_frame": float(stats[:, 1:3].sum().item()) / max(total_frames, 1),
+        "model_tflops": FLOP_PER_FRAME * fps / 1e12,
+        "mfma_fraction_end_to_end": FLOP_PER_FRAME * fps / world / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+    }
+    if timer is not None:
+        summ = timer.summary()
+        g = summ.get("gemm_nt_f32")
+        if g and g["ms"] > 0:
+            ach = g["work"] / (g["ms"] * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "gemm_nt_f32_kernel", "bound": "mfma", "achieved": ach,
+                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                  "launches": g["launches"], "avg_launch_ms": g["ms"] / g["launches"],
+                                  "gemm_ms_per_step": g["ms"] / args.steps}
+        a = summ.get("window_attention_f32")
+        if a and a["ms"] > 0:
+            result["attention"] = {"kernel": "window_attention_f32_kernel",
+                                   "achieved_tflops": a["work"] / (a["ms"] * 1e-3) / 1e12,
+                                   "launches": a["launches"], "ms_per_step": a["ms"] / args.steps}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args.quality, os.cpu_count() or 1)
+        except Exception as e:  # noqa: BLE001
+            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). "
                 "Run `python -m cra5_amd.build` (hipcc, gfx950).")
+        # torch must be loaded first: it bundles its own HIP runtime (libamdhip64.so.7 in
+        # torch/lib); loading ours first would pull /opt/rocm's copy under the same SONAME and
+        # torch then fails with hipErrorNoDevice (two runtimes, one process).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the header and the library disagree

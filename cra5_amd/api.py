@@ -1,0 +1,218 @@
+"""`cra5_api` - the user API of the reference (cra5/api/cra5_api.py:22-341 in
+taohan10200/CRA5) on top of the MI355X-native VAEformer.
+
+Same class / method names, argument meaning, returned dict keys and on-disk layout
+(`{local_root}/ERA5/{yyyy}/{ts}_{pressure,single}.nc` in, `{save_root}/{yyyy}/{ts}.bin`
+out).  Conscious differences:
+  * the CDS downloader (network, credentials in the reference source) is created lazily,
+    only when `download_era5_data` is called, and only if `cdsapi` is importable;
+  * every method that takes a `time_stamp` also accepts an in-memory array/tensor
+    `data=` (268x721x1440, physical units) - the GPU box has neither NetCDF files nor
+    xarray;
+  * `weights=` lets the caller pass a ready model (synthetic weights offline); the
+    default tries the reference checkpoint and raises the reference's error if absent;
+  * normalisation is fused into the patch gather and de-normalisation into the
+    overlap-add store (one pass over the 1.1 GB frame instead of two);
+  * the reference's `return_format='de_normlized'` default typo (returns None) is kept
+    as an accepted alias of 'de_normalized' rather than reproduced.
+"""
+import json
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import binfmt
+from .zoo import vaeformer_pretrained
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class cra5_api:
+    def __init__(self, config=None, local_root=None, device=None, ceph_cfg=None, weights=None, quality=268):
+        self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
+        print(f'The serving device is {self.device}')
+        with open(os.path.join(_HERE, "data", "era5_stats.json")) as f:
+            self._stats = json.load(f)
+        self.vnames = dict(pressure=list(self._stats["pressure"]), single=list(self._stats["single"]))
+        self.total_levels = list(self._stats["total_levels"])
+        self.pressure_level = list(self.total_levels)  # cra5_268v_config.py:48-54
+        if config is not None:  # a reference-style python config may override vnames / levels
+            ns = {}
+            exec(compile(open(config).read(), config, "exec"), ns)  # noqa: S102 (user-supplied config file)
+            self.vnames = ns.get("vnames", self.vnames)
+            self.pressure_level = ns.get("pressure_level", self.pressure_level)
+        self.level_mapping = [self.total_levels.index(v) for v in self.pressure_level if v in self.total_levels]
+        mean, std = self.get_mean_std()
+        self.mean = torch.from_numpy(mean[:, np.newaxis, np.newaxis]).to(self.device)
+        self.std = torch.from_numpy(std[:, np.newaxis, np.newaxis]).to(self.device)
+        self._mean_flat = self.mean.reshape(-1).contiguous()
+        self._std_flat = self.std.reshape(-1).contiguous()
+        self.channels_to_vname, self.vname_to_channels = self.channel_vname_mapping()
+        self.local_root = local_root or f'{os.getcwd()}/data'
+        self._era5 = None
+        if weights is not None:
+            self.net = weights.eval().to(self.device)
+        else:
+            self.net = vaeformer_pretrained(quality=quality, pretrained=True).eval().to(self.device)
+
+    # ------------------------------------------------------------------ ingest
+    def download_era5_data(self, time_stamp=None, save_root=None, data_formate="nc"):
+        raise RuntimeError("ERA5 download needs network access + the CDS API (out of scope offline); "
+                           "place the NetCDF files under {local_root}/ERA5/{yyyy}/ or pass data=")
+
+    def read_data_from_nc(self, time_stamp):
+        """cra5_api.py:195-226: (268, 721, 1440) float32, pressure vars x levels then singles,
+        tp scaled by 1000."""
+        try:
+            import xarray as xr
+        except ImportError as e:  # pragma: no cover
+            raise RuntimeError("reading ERA5 NetCDF needs xarray + netCDF4; pass data= instead") from e
+        one_step = []
+        pressure_file = f'{self.local_root}/ERA5/{time_stamp[:4]}/{time_stamp}_pressure.nc'
+        single_file = f'{self.local_root}/ERA5/{time_stamp[:4]}/{time_stamp}_single.nc'
+        pressure_data = xr.open_dataset(pressure_file, engine='netcdf4')
+        single_data = xr.open_dataset(single_file, engine='netcdf4')
+        for vname in self.vnames['pressure']:
+            D = pressure_data[vname].data
+            pha = list(pressure_data.level.data)
+            for level in [pha.index(v) for v in self.pressure_level if v in pha]:
+                one_step.append(D[0][level][None])
+        for vname in self.vnames['single']:
+            D = single_data[vname].data
+            if vname == 'tp':
+                D = D * 1000
+            one_step.append(D)
+        return np.concatenate(one_step, 0)
+
+    def _frame(self, time_stamp, data):
+        if data is None:
+            data = self.read_data_from_nc(time_stamp)
+        if not isinstance(data, torch.Tensor):
+            data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+        return data.to(self.device, dtype=torch.float32)
+
+    def channel_vname_mapping(self):
+        """cra5_api.py:228-241."""
+        c2v, v2c = {}, {}
+        ch = 0
+        for v in self.vnames['pressure']:
+            for level in self.pressure_level:
+                c2v[ch] = v + '_' + str(int(level))
+                v2c[v + '_' + str(int(level))] = ch
+                ch += 1
+        for v in self.vnames['single']:
+            c2v[ch] = v
+            v2c[v] = ch
+            ch += 1
+        return c2v, v2c
+
+    def get_mean_std(self):
+        """cra5_api.py:243-261."""
+        mean_list, std_list = [], []
+        for v in self.vnames['pressure']:
+            mean_list += [self._stats['mean'][v][i] for i in self.level_mapping]
+            std_list += [self._stats['std'][v][i] for i in self.level_mapping]
+        for v in self.vnames['single']:
+            mean_list.append(self._stats['mean'][v])
+            std_list.append(self._stats['std'][v])
+        return np.array(mean_list, dtype=np.float32), np.array(std_list, dtype=np.float32)
+
+    def normalization(self, data):
+        """cra5_api.py:264-266 (stand-alone form; the hot path fuses it into the patch gather)."""
+        return (data - self.mean) / self.std
+
+    def de_normalization(self, data):
+        """cra5_api.py:268-271: in place, like the reference."""
+        data *= self.std
+        data += self.mean
+        return data
+
+    # ------------------------------------------------------------------ encode
+    def _encode_y(self, frame):
+        """normalise + g_a + quant_conv for one physical-units frame (fused normalisation)."""
+        with torch.no_grad():
+            self.net._require_gpu()
+            return self.net._encode_y_frame(frame, mean=self._mean_flat, std=self._std_flat)
+
+    def encode_to_latent(self, time_stamp=None, save_root=None, latent_type='float', data=None):
+        """cra5_api.py:53-71."""
+        frame = self._frame(time_stamp, data)
+        with torch.no_grad():
+            y = self._encode_y(frame)
+            if latent_type == 'float':
+                return y.unsqueeze(0)
+            if latent_type == 'quantized':
+                s = self.net._latent_side_frame(y)
+                return s["y_hat"].reshape(y.shape).unsqueeze(0)
+
+    def latent_to_bin(self, y, save_root=None):
+        """cra5_api.py:73-79."""
+        with torch.no_grad():
+            return self.net.compress_from_latent(y)
+
+    def encode_era5_as_bin(self, time_stamp, save_root=None, return_format='bin', data=None):
+        """cra5_api.py:81-125."""
+        save_root = save_root or self.local_root
+        st1 = time.time()
+        frame = self._frame(time_stamp, data)
+        st2 = time.time()
+        with torch.no_grad():
+            y = self._encode_y(frame)
+            if return_format == 'latent':
+                return y.unsqueeze(0)
+            if return_format == 'quantized':
+                s = self.net._latent_side_frame(y)
+                return s["y_hat"].reshape(y.shape).unsqueeze(0)
+            output = self.net.compress_from_latent(y.unsqueeze(0))
+        st3 = time.time()
+        year = time_stamp.split('-')[0]
+        file_url = f'{save_root}/{year}/{time_stamp}.bin'
+        os.makedirs(os.path.dirname(file_url), exist_ok=True)
+        with Path(file_url).open("wb") as f:
+            f.write(binfmt.pack_bin(output["strings"], output["z_shape"]))
+        st4 = time.time()
+        return dict(output=output, reading_time=st2 - st1, encoding_time=st3 - st2, saving_time=st4 - st3,
+                    save_path=file_url)
+
+    # ------------------------------------------------------------------ decode
+    def _read_bin(self, bin_path):
+        with Path(bin_path).open("rb") as f:
+            return binfmt.unpack_bin(f.read())
+
+    def bin_to_latent(self, bin_path=None, time_stamp=None):
+        """cra5_api.py:127-144 (the reference's default path uses an undefined `time_stamp`;
+        it is an explicit argument here)."""
+        if bin_path is None:
+            if time_stamp is None:
+                raise ValueError("bin_to_latent needs bin_path or time_stamp")
+            bin_path = f'{self.local_root}/CRA5/{time_stamp[:4]}/{time_stamp}.bin'
+        lstrings, shape = self._read_bin(bin_path)
+        with torch.no_grad():
+            return self.net.decompress(lstrings, shape, return_format='latent')
+
+    def latent_to_reconstruction(self, y_hat):
+        """cra5_api.py:146-151 (normalised units)."""
+        with torch.no_grad():
+            return self.net.decode_latent(y_hat)
+
+    def decode_from_bin(self, time_stamp=None, custom_path=None, return_format='de_normalized'):
+        """cra5_api.py:153-192."""
+        bin_path = custom_path or f'{self.local_root}/CRA5/{time_stamp[:4]}/{time_stamp}.bin'
+        decoding_start = time.time()
+        lstrings, shape = self._read_bin(bin_path)
+        with torch.no_grad():
+            y_hat = self.net.decompress(lstrings, shape, return_format='latent')
+            if return_format == 'latent':
+                return y_hat
+            if return_format == 'normalized':
+                x_hat = self.net.decode_latent(y_hat)
+            elif return_format in ('de_normalized', 'de_normlized'):
+                # fused de-normalisation in the overlap-add store
+                x_hat = self.net._decode_frame(y_hat[0], mean=self._mean_flat, std=self._std_flat)
+            else:
+                raise ValueError(f"unknown return_format {return_format!r}")
+        torch.cuda.synchronize()
+        return dict(x_hat=x_hat, decoding_time=time.time() - decoding_start)

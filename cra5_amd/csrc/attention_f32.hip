@@ -24,7 +24,7 @@
 //     k-slot h is given the d-range [h*HD/2, (h+1)*HD/2): K fragments are contiguous
 //     ds_read_b128 reads from a [32][HD+4] LDS image (pad 4 -> conflict-free), Q lives
 //     in HD/2 registers per lane for the whole kernel (pre-multiplied by the softmax
-//     scale exactly like the reference's `q * self.scale`).
+//     scale, like the reference's `q * self.scale`, times log2 e so exp() is v_exp_f32).
 //   * K/V tiles of 32 keys are prefetched into VGPRs during the previous tile's 64
 //     MFMAs (4096 cycles) and written to LDS between two barriers.
 //   * waves whose 32 queries are all padding (bottom half of the lower (48,12) windows)
@@ -96,6 +96,11 @@ __global__ __launch_bounds__(NW * 64) void window_attention_f32_kernel(
   // a q-tile made only of padding (lower (48,12) windows) has nothing to do at all
   if (!__syncthreads_or(wave_active ? 1 : 0)) return;
 
+  // Scores are kept in the log2 domain: q is pre-multiplied by scale * log2(e) (one
+  // rounding per element, like the reference's `q * self.scale`), so the softmax
+  // exponential is a bare v_exp_f32 of an exact difference - no |x| * 2^-24 argument
+  // error from an extra multiply inside exp().
+  const float qs = scale * 1.44269504088896340736f;
   float q[HH];
   {
     const float *qrow = (q_tok >= 0) ? qkv + (size_t)q_tok * C3 : pad_row;
@@ -103,10 +108,10 @@ __global__ __launch_bounds__(NW * 64) void window_attention_f32_kernel(
 #pragma unroll
     for (int i = 0; i < HH / 4; ++i) {
       const float4 v = *reinterpret_cast<const float4 *>(src + 4 * i);
-      q[4 * i + 0] = v.x * scale;
-      q[4 * i + 1] = v.y * scale;
-      q[4 * i + 2] = v.z * scale;
-      q[4 * i + 3] = v.w * scale;
+      q[4 * i + 0] = v.x * qs;
+      q[4 * i + 1] = v.y * qs;
+      q[4 * i + 2] = v.z * qs;
+      q[4 * i + 3] = v.w * qs;
     }
   }
 
@@ -187,11 +192,11 @@ __global__ __launch_bounds__(NW * 64) void window_attention_f32_kernel(
       for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float m_new = fmaxf(m_run, mloc);
-      const float alpha = __expf(m_run - m_new);  // first tile: exp(-inf) = 0
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: 2^-inf = 0
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = __expf(s[r] - m_new);
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
         psum += s[r];
       }
       l_run = l_run * alpha + psum;  // per-half partial sum; halves are merged at the end

@@ -15,6 +15,52 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Per-launch device timing with HIP events recorded on the launch stream
+    (cra5_event_* in the C ABI).  Used by bench.py for the `roofline` object: it brackets
+    every launch of one kernel family, so sum(work) / sum(duration) is that kernel's
+    achieved rate over the timed region."""
+
+    def __init__(self):
+        self.records = {}   # kind -> list of (start_ev, stop_ev, work)
+        self._free = []
+
+    def _ev(self):
+        if self._free:
+            return self._free.pop()
+        e = ctypes.c_void_p()
+        check(lib().cra5_event_create(ctypes.byref(e)), "cra5_event_create")
+        return e
+
+    def start(self):
+        e = self._ev()
+        check(lib().cra5_event_record(e, _stream()), "cra5_event_record")
+        return e
+
+    def stop(self, kind, start_ev, work):
+        e = self._ev()
+        check(lib().cra5_event_record(e, _stream()), "cra5_event_record")
+        self.records.setdefault(kind, []).append((start_ev, e, work))
+
+    def summary(self):
+        """kind -> dict(launches, work, ms). Synchronises on the recorded events."""
+        out = {}
+        for kind, recs in self.records.items():
+            ms_tot, work = 0.0, 0.0
+            for s, e, w in recs:
+                ms = ctypes.c_float()
+                check(lib().cra5_event_elapsed_ms(s, e, ctypes.byref(ms)), "cra5_event_elapsed_ms")
+                ms_tot += ms.value
+                work += w
+                self._free += [s, e]
+            out[kind] = dict(launches=len(recs), work=work, ms=ms_tot)
+        self.records = {}
+        return out
+
+
+TIMER = None  # set to a KernelTimer by bench.py
+
+
 def _dev(*ts):
     for t in ts:
         if t is None:
@@ -44,9 +90,12 @@ def gemm_nt(a, w, bias=None, res=None, gelu=False, out=None):
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
+    ev = TIMER.start() if TIMER is not None else None
     check(lib().cra5_gemm_nt_f32(_p(a), _row_stride(a), _p(w), _row_stride(w), _p(out), _row_stride(out), _p(bias),
                                  _p(res), _row_stride(res) if res is not None else 0, M, N, K, flags, _stream()),
           "cra5_gemm_nt_f32")
+    if ev is not None:
+        TIMER.stop("gemm_nt_f32", ev, 2.0 * M * N * K)
     return out
 
 
@@ -70,8 +119,13 @@ def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None):
         out = torch.empty((N, C), device=qkv.device, dtype=torch.float32)
     assert out.is_contiguous()
     scale = float((C // heads) ** -0.5)
+    ev = TIMER.start() if TIMER is not None else None
     check(lib().cra5_window_attention_f32(_p(qkv), _p(pad_row), _p(out), C, heads, H, W, wh, ww, scale, _stream()),
           "cra5_window_attention_f32")
+    if ev is not None:
+        # algorithmic flops: real (unpadded) queries x all keys of their window, QK^T + PV
+        L = wh * ww
+        TIMER.stop("window_attention_f32", ev, 4.0 * N * L * C)
     return out
 
 

@@ -91,3 +91,38 @@ def synth_frame(channels, seed, H=721, W=1440, kind="normal"):
     if kind == "uniform":
         return torch.rand((channels, H, W), generator=g, dtype=torch.float32)
     return torch.randn((channels, H, W), generator=g, dtype=torch.float32)
+
+
+def thin_model_kwargs():
+    """Constructor arguments (reference signature, vaeformer.py:78-92) of the thin-width,
+    full-spatial test model: 8 variables, width 128 (2 heads x 64), latent 16, hyper-prior
+    width 144 (2 heads x 72) - same head dims, window pattern and 721x1440 geometry as the
+    268 model at ~1/1000 of the FLOPs."""
+    dd_kw = dict(z_dim=None, learnable_pos=True, window=True, window_size=[(24, 24), (12, 48), (48, 12)], interval=4,
+                 drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                 test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=True, img_size=(721, 1440),
+                 embed_dim=128, depth=8, num_heads=2)
+    prior_kw = dict(z_dim=16, embed_dim=144, depth=4, num_heads=2, interval=1, learnable_pos=True, window=False,
+                    drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                    test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=False, img_size=(72, 144))
+    return dict(embed_dim=16, z_channels=16, y_channels=128, sample_posterior=False, frozen_encoder=False,
+                lower_dim=True,
+                ddconfig=dict(arch='vit_base', patch_size=(11, 10), patch_stride=(10, 10), in_chans=8, out_chans=8,
+                              pretrained_model='', kwargs=dd_kw),
+                priorconfig=dict(patch_size=(4, 4), in_chans=16, out_chans=16, pretrained_model='', kwargs=prior_kw))
+
+
+@torch.no_grad()
+def load_synthetic(net, seed=0, update=True):
+    """Fill `net` (a VAEformer) with the deterministic synthetic weights and build its CDF
+    tables (`update(force=True)`)."""
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = fill_state_dict(shapes, seed)
+    own = net.state_dict()
+    for k, v in sd.items():
+        own[k].copy_(v)
+    if hasattr(net, "_derived"):
+        net._derived.clear()
+    if update:
+        net.update(force=True)
+    return net

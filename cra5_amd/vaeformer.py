@@ -1,0 +1,602 @@
+"""VAEformer codec model on MI355X: same object surface and state-dict layout as the
+reference's `cra5.models.vaeformer.vaeformer.VAEformer` (vaeformer.py:70-403 in
+taohan10200/CRA5), every tensor op executed by the hand-written HIP kernels of
+`libcra5_amd.so` through the C ABI.  torch is used for parameter storage, device
+buffers and streams only.
+
+Reference behaviour kept on purpose:
+  * block pattern W(24,24), W(12,48), W(48,12), G repeated, the duplicated last encoder
+    block producing `mean` / `logvar` from the same input (vit_nlc.py:401-422, 463-475);
+  * (48,12) windows zero-pad the 72-row grid to 96 AFTER norm1 / BEFORE qkv, unmasked
+    (vit_nlc.py:229-246) - implemented inside the attention kernel (padded tokens read the
+    qkv bias), so no padded GEMM rows are ever computed;
+  * `y` = first half of quant_conv's output (posterior.mode()); the logvar half is dead
+    work in the reference (distributions.py:24-33) and is simply not computed here;
+  * z is "decoded" on the encode side so both sides see the same z_hat
+    (vaeformer.py:365-366): de-quantising the symbols is bit-identical to decoding the
+    stream (lossless coder), so the encode side skips the redundant rANS decode.
+There is no CPU path: on a non-GPU device every compute method raises.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .entropy import EntropyBottleneck, GaussianConditional, get_scale_table
+
+__all__ = ["VAEformer", "config_for", "block_windows"]
+
+
+# --------------------------------------------------------------------------------------
+# configuration
+# --------------------------------------------------------------------------------------
+
+_DD_KW_268 = dict(z_dim=None, learnable_pos=True, window=True, window_size=[(24, 24), (12, 48), (48, 12)], interval=4,
+                  drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                  test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=True, img_size=(721, 1440))
+_PRIOR_KW_268 = dict(z_dim=256, embed_dim=360, depth=8, num_heads=5, interval=1, learnable_pos=True, window=False,
+                     drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                     test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=False, img_size=(72, 144))
+_ARCH = dict(vit_base=dict(embed_dim=768, depth=12, num_heads=12),
+             vit_large=dict(embed_dim=1024, depth=24, num_heads=16),
+             vit_huge=dict(embed_dim=2048, depth=24, num_heads=16))  # vit_nlc.py:1000-1024
+
+
+def config_for(model_version, embed_dim=None, z_channels=None, y_channels=None, ddconfig=None, priorconfig=None):
+    """Resolve the reference's constructor arguments (vaeformer.py:78-142) into one flat
+    dict.  model_version 268 is the reference's hard-wired model; 159 is the same
+    architecture with 159 variables (config/vaeformer_era5_159v_1h.py) - the reference's
+    zoo raises for it, we provide it."""
+    if model_version in (268, 159):
+        embed_dim, z_channels, y_channels = 256, 256, 1024
+        ddconfig = dict(arch='vit_large', patch_size=(11, 10), patch_stride=(10, 10), in_chans=model_version,
+                        out_chans=model_version, kwargs=dict(_DD_KW_268))
+        priorconfig = dict(patch_size=(4, 4), in_chans=256, out_chans=256, kwargs=dict(_PRIOR_KW_268))
+    if ddconfig is None or priorconfig is None:
+        raise ValueError("VAEformer: model_version must be 268/159 or ddconfig/priorconfig must be given")
+    dd = dict(_ARCH[ddconfig.get('arch', 'vit_base')])
+    ddk = dict(ddconfig.get('kwargs') or {})
+    dd.update({k: ddk[k] for k in ('embed_dim', 'depth', 'num_heads') if k in ddk})
+    pr = dict(embed_dim=768, depth=12, num_heads=12)  # vit_nlc.py:1075-1082
+    prk = dict(priorconfig.get('kwargs') or {})
+    pr.update({k: prk[k] for k in ('embed_dim', 'depth', 'num_heads') if k in prk})
+    ps = tuple(ddconfig['patch_size'])
+    cfg = dict(
+        in_chans=ddconfig['in_chans'], out_chans=ddconfig.get('out_chans', ddconfig['in_chans']),
+        img_size=tuple(ddk.get('img_size', (721, 1440))), patch_size=ps,
+        patch_stride=tuple(ddconfig.get('patch_stride') or ps),
+        embed_dim=dd['embed_dim'], depth=dd['depth'], num_heads=dd['num_heads'],
+        window_size=[tuple(w) for w in ddk.get('window_size', [(24, 24), (12, 48), (48, 12)])],
+        interval=ddk.get('interval', 4), window=ddk.get('window', True),
+        latent_dim=embed_dim, y_channels=y_channels, z_channels=z_channels,
+        h_patch=tuple(priorconfig['patch_size']), h_in_chans=priorconfig['in_chans'],
+        h_embed_dim=pr['embed_dim'], h_depth=pr['depth'], h_num_heads=pr['num_heads'],
+        z_dim=prk.get('z_dim'), h_img_size=tuple(prk.get('img_size', (72, 144))),
+    )
+    if cfg['y_channels'] != cfg['embed_dim']:
+        raise ValueError("y_channels must equal the encoder width (quant_conv input is 2*y_channels)")
+    return cfg
+
+
+def block_windows(first, last, interval, window_size, window=True):
+    """vit_nlc.py:401-411 / :613-623: block i is windowed iff (i+1) % interval != 0."""
+    out = []
+    for i in range(first, last):
+        if window and (i + 1) % interval != 0:
+            out.append(tuple(window_size[min(i % interval, len(window_size) - 1)]))
+        else:
+            out.append(None)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# parameter containers (names = reference state-dict keys)
+# --------------------------------------------------------------------------------------
+
+
+def _trunc_normal(shape, std=0.02):
+    t = torch.empty(shape)
+    nn.init.trunc_normal_(t, std=std)
+    return t
+
+
+class _Linear(nn.Module):
+    def __init__(self, fin, fout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(_trunc_normal((fout, fin)))
+        self.bias = nn.Parameter(torch.zeros(fout)) if bias else None
+
+
+class _LayerNorm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _Conv(nn.Module):
+    def __init__(self, wshape, bias_n=None):
+        super().__init__()
+        fan_in = int(np.prod(wshape[1:]))
+        bound = 1.0 / math.sqrt(fan_in)
+        self.weight = nn.Parameter(torch.empty(wshape).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(bias_n).uniform_(-bound, bound)) if bias_n else None
+
+
+class _Mlp(nn.Module):
+    def __init__(self, fin, hidden, fout):
+        super().__init__()
+        self.fc1 = _Linear(fin, hidden)
+        self.fc2 = _Linear(hidden, fout)
+
+
+class _Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.qkv = _Linear(d, 3 * d)
+        self.proj = _Linear(d, d)
+
+
+class _Block(nn.Module):
+    def __init__(self, d, heads, window, layer_id):
+        super().__init__()
+        self.norm1 = _LayerNorm(d)
+        self.attn = _Attn(d)
+        self.norm2 = _LayerNorm(d)
+        self.mlp = _Mlp(d, 4 * d, d)
+        self.heads = heads
+        self.window = window  # (wh, ww) or None = global
+        with torch.no_grad():  # fix_init_weight, vit_nlc.py:438-444
+            self.attn.proj.weight.div_(math.sqrt(2.0 * layer_id))
+            self.mlp.fc2.weight.div_(math.sqrt(2.0 * layer_id))
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, cin, d, k):
+        super().__init__()
+        self.proj = _Conv((d, cin, k[0], k[1]), d)
+
+
+def _sincos_pos_embed(d, grid):
+    """get_2d_sincos_pos_embed, vit_nlc.py:906-956 (w goes first)."""
+    gh, gw = grid
+    ys, xs = np.meshgrid(np.arange(gh, dtype=np.float32), np.arange(gw, dtype=np.float32), indexing="ij")
+
+    def one(dim, pos):
+        omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float32) / (dim / 2.0))
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+    emb = np.concatenate([one(d // 2, xs), one(d // 2, ys)], axis=1)
+    return torch.from_numpy(emb).float().unsqueeze(0)
+
+
+class _Encoder(nn.Module):
+    """State of ViT_Encoder / HyperpriorEncoder (vit_nlc.py:328-551)."""
+
+    def __init__(self, cin, d, heads, patch, grid, windows, z_dim=None):
+        super().__init__()
+        self.pos_embed = nn.Parameter(_sincos_pos_embed(d, grid))
+        self.patch_embed = _PatchEmbed(cin, d, patch)
+        self.blocks = nn.ModuleList([_Block(d, heads, w, i + 1) for i, w in enumerate(windows)])
+        if z_dim is not None:  # vit_nlc.py:543-546
+            self.quan_mlp = _Mlp(d, int(np.sqrt(d // z_dim)) * z_dim, z_dim)
+
+
+class _Decoder(nn.Module):
+    """State of ViT_Decoder / HyperpriorDecoder (vit_nlc.py:553-748)."""
+
+    def __init__(self, d, heads, windows, final, z_dim=None):
+        super().__init__()
+        if z_dim is not None:  # vit_nlc.py:608-611
+            self.post_quan_mlp = _Mlp(z_dim, int(np.sqrt(d // z_dim)) * z_dim, d)
+        self.blocks = nn.ModuleList([_Block(d, heads, w, i + 1) for i, w in enumerate(windows)])
+        self.norm = _LayerNorm(d)
+        self.final = final
+
+
+class _Posterior:
+    """The slice of DiagonalGaussianDistribution the path uses (distributions.py:24-67)."""
+
+    def __init__(self, mean):
+        self.mean = mean
+
+    def mode(self):
+        return self.mean
+
+
+# --------------------------------------------------------------------------------------
+# the model
+# --------------------------------------------------------------------------------------
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class VAEformer(nn.Module):
+    def __init__(self, model_version, embed_dim=None, z_channels=None, y_channels=None, sample_posterior=None,
+                 pretrained_vae=None, frozen_encoder=None, ddconfig=None, priorconfig=None,
+                 rate_distortion_loss=None, kl_loss=None, ignore_keys=(), lower_dim=False, **kwargs):
+        super().__init__()
+        if sample_posterior:
+            raise NotImplementedError("sample_posterior=True is a training feature (vaeformer.py:279-280)")
+        cfg = config_for(model_version, embed_dim, z_channels, y_channels, ddconfig, priorconfig)
+        self.cfg = cfg
+        self.sample_posterior = False
+        self.lower_dim = True
+        self.frozen_encoder = bool(frozen_encoder)
+        D, L = cfg['embed_dim'], cfg['latent_dim']
+        H, W = cfg['img_size']
+        kh, kw = cfg['patch_size']
+        sh, sw = cfg['patch_stride']
+        self.Hp, self.Wp = H // sh, W // sw  # vit_nlc.py:299, 598
+        if (self.Hp - 1) * sh + kh != H or (self.Wp - 1) * sw + kw != W:
+            raise ValueError("img_size must be tiled exactly by the (overlapping) patches")
+        zh, zw = cfg['h_patch']
+        self.Hz, self.Wz = self.Hp // zh, self.Wp // zw
+
+        enc_w = block_windows(0, cfg['depth'] // 2, cfg['interval'], cfg['window_size'], cfg['window'])
+        enc_w = enc_w + [enc_w[-1]]  # vit_nlc.py:413-422
+        dec_w = block_windows(cfg['depth'] // 2, cfg['depth'], cfg['interval'], cfg['window_size'], cfg['window'])
+
+        self.entropy_bottleneck = EntropyBottleneck(cfg['z_channels'])
+        self.g_a = _Encoder(cfg['in_chans'], D, cfg['num_heads'], (kh, kw), (self.Hp, self.Wp), enc_w)
+        self.g_s = _Decoder(D, cfg['num_heads'], dec_w, _Conv((D, cfg['out_chans'], kh, kw)))
+        self.quant_conv = _Conv((2 * L, 2 * cfg['y_channels'], 1, 1), 2 * L)
+        self.post_quant_conv = _Conv((cfg['y_channels'], L, 1, 1), cfg['y_channels'])
+        hd, hh = cfg['h_embed_dim'], cfg['h_num_heads']
+        n_h = cfg['h_depth'] // 2
+        self.h_a = _Encoder(cfg['h_in_chans'], hd, hh, (zh, zw), (self.Hz, self.Wz), [None] * n_h, cfg['z_dim'])
+        self.h_s = _Decoder(hd, hh, [None] * (cfg['h_depth'] - n_h),
+                            _Linear(hd, 2 * cfg['h_in_chans'] * zh * zw, bias=False), cfg['z_dim'])
+        self.gaussian_conditional = GaussianConditional(None)
+        self._derived = {}
+        self._ws = {}
+        self.eval()
+
+    # ---- reference-compatible loading (vaeformer.py:168-185, base.py:69-89) -------------
+    @classmethod
+    def from_state_dict(cls, state_dict):
+        variable_num = state_dict["backbone.g_a.patch_embed.proj.weight"].size(1)
+        new_sd = OrderedDict()
+        for k, v in state_dict.items():
+            if 'kl_loss.logvar' not in k:
+                new_sd[k.replace("backbone.", "")] = v
+        net = cls(variable_num)
+        net.load_state_dict(new_sd)
+        return net
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Resizes the CDF buffers to the checkpoint's (models/base.py:69-89)."""
+        for name, names in (("entropy_bottleneck", ("_quantized_cdf", "_offset", "_cdf_length")),
+                            ("gaussian_conditional", ("_quantized_cdf", "_offset", "_cdf_length", "scale_table"))):
+            mod = getattr(self, name)
+            for b in names:
+                key = f"{name}.{b}"
+                if key in state_dict:
+                    buf = getattr(mod, b)
+                    if buf.numel() == 0:
+                        buf.resize_(state_dict[key].size())
+        self._derived.clear()
+        return nn.Module.load_state_dict(self, state_dict, strict=strict)
+
+    def update(self, scale_table=None, force=False):
+        """CompressionModel.update (models/base.py:91-115)."""
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.entropy_bottleneck.update(force=force)
+        updated |= self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        return updated
+
+    @property
+    def downsampling_factor(self):
+        return 2 ** (4 + 2)
+
+    # ---- device plumbing ---------------------------------------------------------------
+    @property
+    def device(self):
+        return self.quant_conv.weight.device
+
+    def _require_gpu(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("cra5_amd.VAEformer computes only on an MI355X (HIP kernels, no CPU fallback). "
+                               "Move the model with .to('cuda'); the CPU restatement lives in oracle/ (tests only).")
+
+    def _buf(self, name, shape, dtype=torch.float32, zero=False):
+        """Persistent workspace (allocated once per device)."""
+        key = (name, tuple(shape), dtype, str(self.device))
+        b = self._ws.get(name)
+        if b is None or b[0] != key:
+            t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
+            self._ws[name] = (key, t)
+            return t
+        return b[1]
+
+    def _derive(self, name, src, fn):
+        """GEMM-ready re-layouts of weights, cached until the parameter changes."""
+        key = (src.data_ptr(), src._version, str(src.device))
+        d = self._derived.get(name)
+        if d is None or d[0] != key:
+            with torch.no_grad():
+                d = (key, fn(src.detach()))
+            self._derived[name] = d
+        return d[1]
+
+    def _w_patch_embed(self):
+        """Conv2d(C -> D, k=(11,10)) as W[D][K_pad], K = C*110 zero-padded to a multiple of 32."""
+        w = self.g_a.patch_embed.proj.weight
+
+        def mk(w):
+            D = w.shape[0]
+            K = w[0].numel()
+            out = torch.zeros((D, _rup(K, 32)), device=w.device, dtype=torch.float32)
+            out[:, :K] = w.reshape(D, K)
+            return out
+        return self._derive("w_pe", w, mk)
+
+    def _w_unembed(self):
+        """ConvTranspose2d(D -> C, k=(11,10)) weight (D, C, kh, kw) as W[N = C*110][K = D]."""
+        w = self.g_s.final.weight
+        return self._derive("w_ue", w, lambda w: w.reshape(w.shape[0], -1).t().contiguous())
+
+    # ---- transformer block on device -----------------------------------------------------
+    def _block(self, blk, t_in, t_out, grid):
+        """vit_nlc.py:282-287. t_in: [N, D] input; t_out: [N, D] (may be t_in, may be a strided
+        view) receives x + attn(LN(x)) + mlp(LN(.))."""
+        N, D = t_in.shape
+        H, W = grid
+        h = self._buf(f"h{D}", (N, D))
+        qkv = self._buf(f"qkv{D}", (N, 3 * D))
+        att = self._buf(f"att{D}", (N, D))
+        hid = self._buf(f"hid{D}", (N, 4 * D))
+        ops.layernorm(t_in, blk.norm1.weight, blk.norm1.bias, 1e-6, out=h)
+        ops.gemm_nt(h, blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out=qkv)
+        wh, ww = blk.window if blk.window is not None else (H, W)
+        ops.window_attention(qkv, blk.attn.qkv.bias, blk.heads, H, W, wh, ww, out=att)
+        ops.gemm_nt(att, blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
+        ops.layernorm(t_out, blk.norm2.weight, blk.norm2.bias, 1e-6, out=h)
+        ops.gemm_nt(h, blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias, gelu=True, out=hid)
+        ops.gemm_nt(hid, blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias, res=t_out, out=t_out)
+        return t_out
+
+    # ---- g_a + quant_conv -----------------------------------------------------------------
+    def _encode_y_frame(self, x, mean=None, std=None):
+        """x: [C, H, W] on device -> y [L, Hp, Wp] (vaeformer.py:272-282)."""
+        cfg = self.cfg
+        D, L = cfg['embed_dim'], cfg['latent_dim']
+        N = self.Hp * self.Wp
+        kh, kw = cfg['patch_size']
+        sh, sw = cfg['patch_stride']
+        wpe = self._w_patch_embed()
+        cols = self._buf("cols", (N, max(wpe.shape[1], _rup(cfg['out_chans'] * kh * kw, 32))), zero=True)
+        colv = cols[:, : wpe.shape[1]]
+        check = ops.lib().cra5_im2col_f32  # strided destination: call the ABI directly
+        ops._dev(x, mean, std)
+        ops.check(check(ops._p(x.contiguous()), ops._p(mean), ops._p(std), ops._p(cols), cfg['in_chans'],
+                        cfg['img_size'][0], cfg['img_size'][1], kh, kw, sh, sw, self.Hp, self.Wp, cols.stride(0),
+                        ops._stream()), "cra5_im2col_f32")
+        t = self._buf(f"t{D}", (N, D))
+        ops.gemm_nt(colv, wpe, bias=self.g_a.patch_embed.proj.bias, res=self.g_a.pos_embed[0], out=t)
+        blocks = self.g_a.blocks
+        grid = (self.Hp, self.Wp)
+        for blk in blocks[:-2]:
+            self._block(blk, t, t, grid)
+        mom = self._buf("mom", (N, 2 * D))
+        self._block(blocks[-2], t, mom[:, :D], grid)   # mean
+        self._block(blocks[-1], t, mom[:, D:], grid)   # logvar (vit_nlc.py:468-470)
+        wq = self.quant_conv.weight.view(2 * L, 2 * D)[:L]  # only the `mean` half is ever used
+        ytok = self._buf("ytok", (N, L))
+        ops.gemm_nt(mom, wq, bias=self.quant_conv.bias[:L], out=ytok)
+        y = torch.empty((L, self.Hp, self.Wp), device=self.device, dtype=torch.float32)
+        ops.transpose(ytok, out=y.view(L, N))
+        return y
+
+    # ---- hyper-prior ----------------------------------------------------------------------
+    def _h_a_frame(self, y):
+        """y [L, Hp, Wp] -> z [Cz, Hz*Wz] (vit_nlc.py:488-551)."""
+        cfg = self.cfg
+        d = cfg['h_embed_dim']
+        zh, zw = cfg['h_patch']
+        n = self.Hz * self.Wz
+        cols = ops.im2col(y, zh, zw, zh, zw, out=self._buf("hcols", (n, y.shape[0] * zh * zw)))
+        w = self.h_a.patch_embed.proj.weight
+        t = self._buf(f"t{d}", (n, d))
+        ops.gemm_nt(cols, w.view(w.shape[0], -1), bias=self.h_a.patch_embed.proj.bias, res=self.h_a.pos_embed[0], out=t)
+        for blk in self.h_a.blocks:
+            self._block(blk, t, t, (self.Hz, self.Wz))
+        m = self.h_a.quan_mlp
+        u = ops.gemm_nt(t, m.fc1.weight, bias=m.fc1.bias, gelu=True)
+        ztok = ops.gemm_nt(u, m.fc2.weight, bias=m.fc2.bias)
+        return ops.transpose(ztok)  # [Cz, n]
+
+    def _h_s_frame(self, z_hat):
+        """z_hat [Cz, n] -> (scales, means), each [L, Hp, Wp] (vit_nlc.py:696-748, 665-680;
+        chunk order vaeformer.py:369).  Deterministic: same kernels / reduction order on the
+        encode and the decode side."""
+        cfg = self.cfg
+        d = cfg['h_embed_dim']
+        zh, zw = cfg['h_patch']
+        n = self.Hz * self.Wz
+        ztok = ops.transpose(z_hat)  # [n, Cz]
+        m = self.h_s.post_quan_mlp
+        u = ops.gemm_nt(ztok, m.fc1.weight, bias=m.fc1.bias, gelu=True)
+        t = self._buf(f"t{d}", (n, d))
+        ops.gemm_nt(u, m.fc2.weight, bias=m.fc2.bias, out=t)
+        for blk in self.h_s.blocks:
+            self._block(blk, t, t, (self.Hz, self.Wz))
+        h = ops.layernorm(t, self.h_s.norm.weight, self.h_s.norm.bias, 1e-6)
+        lin = ops.gemm_nt(h, self.h_s.final.weight)
+        params = ops.pixel_shuffle(lin, self.Hz, self.Wz, zh, zw)  # [2L, Hp, Wp]
+        L = params.shape[0] // 2
+        return params[:L], params[L:]
+
+    # ---- g_s --------------------------------------------------------------------------------
+    def _decode_frame(self, y_hat, mean=None, std=None):
+        """y_hat [L, Hp, Wp] -> x_hat [C, H, W] (vaeformer.py:294-300)."""
+        cfg = self.cfg
+        D, L = cfg['embed_dim'], cfg['latent_dim']
+        N = self.Hp * self.Wp
+        kh, kw = cfg['patch_size']
+        sh, sw = cfg['patch_stride']
+        ytok = self._buf("ytok", (N, L))
+        ops.transpose(y_hat.reshape(L, N), out=ytok)
+        t = self._buf(f"t{D}", (N, D))
+        ops.gemm_nt(ytok, self.post_quant_conv.weight.view(D, L), bias=self.post_quant_conv.bias, out=t)
+        for blk in self.g_s.blocks:
+            self._block(blk, t, t, (self.Hp, self.Wp))
+        h = self._buf(f"h{D}", (N, D))
+        ops.layernorm(t, self.g_s.norm.weight, self.g_s.norm.bias, 1e-6, out=h)
+        wue = self._w_unembed()
+        ncol = wue.shape[0]
+        wpe_cols = _rup(cfg['in_chans'] * kh * kw, 32)
+        cols = self._buf("cols", (N, max(wpe_cols, _rup(ncol, 32))), zero=True)
+        ops.gemm_nt(h, wue, out=cols[:, :ncol])
+        x_hat = torch.empty((cfg['out_chans'],) + tuple(cfg['img_size']), device=self.device, dtype=torch.float32)
+        ops.col2im(cols[:, :ncol], cfg['out_chans'], kh, kw, sh, sw, self.Hp, self.Wp, mean=mean, std=std, out=x_hat)
+        # the patch-embed path relies on the pad columns of `cols` being zero
+        if cols.shape[1] > ncol and wpe_cols > cfg['in_chans'] * kh * kw:
+            cols[:, cfg['in_chans'] * kh * kw: wpe_cols].zero_()
+        return x_hat
+
+    # ---- latent side: everything between y and the entropy coder ---------------------------
+    def _latent_side_frame(self, y, want_lik=False):
+        z = self._h_a_frame(y)
+        med, pk = self.entropy_bottleneck.device_params()
+        eb = ops.entropy_bottleneck(med, pk, z=z, want=("sym", "z_hat") + (("lik",) if want_lik else ()),
+                                    lik_bound=self.entropy_bottleneck.likelihood_bound)
+        scales, means = self._h_s_frame(eb["z_hat"])
+        st = self.gaussian_conditional.scale_table
+        want = ("idx", "sym", "y_hat") + (("lik",) if want_lik else ())
+        if st.numel() == 0:
+            want = tuple(w for w in want if w != "idx")
+        gc = ops.gaussian_conditional(scales.contiguous(), means.contiguous(), st if st.numel() else None,
+                                      y=y.contiguous(), want=want,
+                                      scale_bound=float(self.gaussian_conditional.lower_bound_scale.bound),
+                                      lik_bound=self.gaussian_conditional.likelihood_bound)
+        return dict(z=z, z_sym=eb["sym"], z_hat=eb["z_hat"], z_lik=eb.get("lik"), scales=scales, means=means,
+                    idx=gc.get("idx"), y_sym=gc["sym"], y_hat=gc["y_hat"], y_lik=gc.get("lik"))
+
+    # ---- public surface (names / return shapes of the reference) ---------------------------
+    @torch.no_grad()
+    def encode_latent(self, x, type='quantized'):
+        """vaeformer.py:272-292 -> (y, y_hat, y_likelihoods)."""
+        self._require_gpu()
+        ys, yh, yl = [], [], []
+        for b in range(x.shape[0]):
+            y = self._encode_y_frame(x[b])
+            ys.append(y)
+            if type == "quantized":
+                s = self._latent_side_frame(y, want_lik=True)
+                yh.append(s["y_hat"].reshape(y.shape))
+                yl.append(s["y_lik"].reshape(y.shape))
+        y = torch.stack(ys)
+        if type == "quantized":
+            return y, torch.stack(yh), torch.stack(yl)
+        return y, None, None
+
+    @torch.no_grad()
+    def decode_latent(self, y, type='quantized'):
+        """vaeformer.py:294-300."""
+        self._require_gpu()
+        return torch.stack([self._decode_frame(y[b]) for b in range(y.shape[0])])
+
+    @torch.no_grad()
+    def forward(self, x):
+        """vaeformer.py:302-333."""
+        self._require_gpu()
+        xh, yl, zl, ys = [], [], [], []
+        for b in range(x.shape[0]):
+            y = self._encode_y_frame(x[b])
+            s = self._latent_side_frame(y, want_lik=True)
+            xh.append(self._decode_frame(s["y_hat"].reshape(y.shape)))
+            yl.append(s["y_lik"].reshape(y.shape))
+            zl.append(s["z_lik"].reshape(-1, self.Hz, self.Wz))
+            ys.append(y)
+        return {"x_hat": torch.stack(xh), "likelihoods": {"y": torch.stack(yl), "z": torch.stack(zl)},
+                "posterior": _Posterior(torch.stack(ys))}
+
+    def _strings_from_side(self, s):
+        self.entropy_bottleneck._check()
+        self.gaussian_conditional._check()
+        z_sym = s["z_sym"].cpu().numpy()
+        y_sym = s["y_sym"].cpu().numpy()
+        idx = s["idx"].cpu().numpy()
+        z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
+        z_str = self.entropy_bottleneck.encode_symbols(z_sym.reshape(-1), z_idx)
+        y_str = self.gaussian_conditional.encode_symbols(y_sym.reshape(-1), idx.reshape(-1))
+        return y_str, z_str
+
+    @torch.no_grad()
+    def compress_from_latent(self, y):
+        """vaeformer.py:334-348."""
+        self._require_gpu()
+        ystr, zstr = [], []
+        for b in range(y.shape[0]):
+            a, c = self._strings_from_side(self._latent_side_frame(y[b].contiguous()))
+            ystr.append(a)
+            zstr.append(c)
+        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
+
+    @torch.no_grad()
+    def compress(self, x):
+        """vaeformer.py:350-376."""
+        self._require_gpu()
+        ystr, zstr = [], []
+        for b in range(x.shape[0]):
+            y = self._encode_y_frame(x[b])
+            a, c = self._strings_from_side(self._latent_side_frame(y))
+            ystr.append(a)
+            zstr.append(c)
+        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
+
+    def _decompress_latent_frame(self, y_string, z_string, shape):
+        eb, gc = self.entropy_bottleneck, self.gaussian_conditional
+        Cz = eb.channels
+        zh, zw = int(shape[0]), int(shape[1])
+        z_idx = eb._build_indexes((1, Cz, zh, zw))
+        z_sym = torch.from_numpy(eb.decode_symbols(z_string, z_idx)).to(self.device).view(Cz, zh * zw)
+        med, _ = eb.device_params()
+        z_hat = ops.entropy_bottleneck(med, None, sym_in=z_sym, want=("z_hat",))["z_hat"]
+        scales, means = self._h_s_frame(z_hat)
+        scales, means = scales.contiguous(), means.contiguous()
+        idx = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=torch.zeros_like(means, dtype=torch.int32),
+                                       want=("idx",), scale_bound=float(gc.lower_bound_scale.bound))["idx"]
+        y_sym = torch.from_numpy(gc.decode_symbols(y_string, idx.cpu().numpy().reshape(-1))).to(self.device)
+        y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym.view(means.shape),
+                                         want=("y_hat",))["y_hat"]
+        return y_hat
+
+    @torch.no_grad()
+    def decompress(self, strings, shape, return_format='reconstructed'):
+        """vaeformer.py:378-400."""
+        self._require_gpu()
+        assert isinstance(strings, list) and len(strings) == 2
+        self.entropy_bottleneck._check()
+        self.gaussian_conditional._check()
+        y_hat = torch.stack([self._decompress_latent_frame(strings[0][b], strings[1][b], shape)
+                             for b in range(len(strings[0]))])
+        if return_format == 'latent':
+            return y_hat
+        return {"x_hat": self.decode_latent(y_hat)}
+
+    @torch.no_grad()
+    def prediction(self, inputs):
+        """vaeformer.py:254-269 (the reference reads out['shape'], a key compress() never
+        sets; we use 'z_shape')."""
+        import time
+        t1 = time.time()
+        out = self.compress(inputs)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        x_hat = self.decompress(out['strings'], out['z_shape'])
+        torch.cuda.synchronize()
+        t3 = time.time()
+        return {**x_hat, "strings": out['strings'], "z_shape": out['z_shape'], 'x_shape': inputs.shape,
+                'encoding_time': (t2 - t1) / inputs.size(0), 'decoding_time': (t3 - t2) / inputs.size(0)}
+
+    def get_last_layer(self):
+        return self.g_s.final.weight

@@ -1,0 +1,78 @@
+"""`vaeformer_pretrained` entry point - mirrors
+cra5/models/compressai/zoo/image.py:302-324 (+ `_load_model` :275-300, `load_pretrained` /
+`rename_key` zoo/pretrained.py:36-64) of the reference.
+
+Differences, stated: quality 159 is accepted (same architecture, 159 variables; the
+reference's zoo raises ValueError for anything but 268); `pretrained=True` cannot download
+(no network) - the checkpoint is read from `$CRA5_WEIGHTS` or
+`~/.cache/torch/hub/checkpoints/cra5_268v_300k.pth` if present, otherwise the reference's
+RuntimeError("Pre-trained model not yet available") is raised.
+"""
+import os
+
+import torch
+
+from .vaeformer import VAEformer
+
+__all__ = ["vaeformer_pretrained", "load_pretrained", "rename_key", "model_architectures", "cfgs"]
+
+model_architectures = {"vaeformer-pretrained": VAEformer}
+cfgs = {"vaeformer-pretrained": {268: (268,), 159: (159,)}}
+_CKPT_NAMES = {268: "cra5_268v_300k.pth"}  # zoo/image.py:69-75
+
+
+def rename_key(key):
+    """zoo/pretrained.py:36-58."""
+    if key.startswith("module."):
+        key = key[7:]
+    if ".downsample." in key:
+        return key.replace("downsample", "skip")
+    if key.startswith("entropy_bottleneck."):
+        if key.startswith("entropy_bottleneck._biases."):
+            return f"entropy_bottleneck._bias{key[-1]}"
+        if key.startswith("entropy_bottleneck._matrices."):
+            return f"entropy_bottleneck._matrix{key[-1]}"
+        if key.startswith("entropy_bottleneck._factors."):
+            return f"entropy_bottleneck._factor{key[-1]}"
+    return key
+
+
+def load_pretrained(state_dict):
+    """zoo/pretrained.py:61-64."""
+    return {rename_key(k): v for k, v in state_dict.items()}
+
+
+def _find_checkpoint(quality):
+    cands = [os.environ.get("CRA5_WEIGHTS")]
+    name = _CKPT_NAMES.get(quality)
+    if name:
+        cands.append(os.path.join(torch.hub.get_dir(), "checkpoints", name))
+    for c in cands:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
+def _load_model(architecture, metric, quality, pretrained=False, progress=True, **kwargs):
+    if architecture not in model_architectures:
+        raise ValueError(f'Invalid architecture name "{architecture}"')
+    if quality not in cfgs[architecture]:
+        raise ValueError(f'Invalid quality value "{quality}"')
+    if pretrained:
+        path = _find_checkpoint(quality) if metric == "mse" else None
+        if path is None:
+            raise RuntimeError("Pre-trained model not yet available")
+        state_dict = torch.load(path, map_location="cpu")
+        if "state_dict" in state_dict:
+            state_dict = state_dict["state_dict"]
+        return model_architectures[architecture].from_state_dict(load_pretrained(state_dict))
+    return model_architectures[architecture](*cfgs[architecture][quality], **kwargs)
+
+
+def vaeformer_pretrained(quality, metric="mse", pretrained=False, progress=True, **kwargs):
+    """zoo/image.py:302-324."""
+    if metric not in ("mse", "ms-ssim"):
+        raise ValueError(f'Invalid metric "{metric}"')
+    if quality < 1 or quality > 999:
+        raise ValueError(f'Invalid quality "{quality}", should be between (1, 999)')
+    return _load_model("vaeformer-pretrained", metric, quality, pretrained, progress, **kwargs)

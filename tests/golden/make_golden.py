@@ -13,6 +13,8 @@ dumps small input/output fixtures (data only) next to this script:
   thin_e2e.npz          full-spatial thin model: every stage of encode / latent side /
                         decode, sub-sampled, + rANS strings
   full268.npz           (--stage full; ~3 min, ~18 GB RAM) the real 268 architecture
+  thin_fp64.npz / full268_fp64.npz  (--stage thin64 / full64) the reference run in float64:
+                        calibration of the fp32 noise floor of the reference itself
 
 Usage:  python tests/golden/make_golden.py --stage small thin [full]
 """
@@ -217,6 +219,12 @@ def run_e2e(net, x, yhat_synth, step_lat, step_img, tag):
         o["y_string"] = np.frombuffer(y_strings[0], dtype=np.uint8)
     import hashlib
     o["y_string_sha256"] = np.frombuffer(hashlib.sha256(y_strings[0]).digest(), dtype=np.uint8)
+    # hyper-decoder given a synthetic, regenerable z_hat (independent of round() flips of z)
+    zs = synth_zhat(z.shape[1], 6) + net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+    p2 = net.h_s(zs)
+    o["hs_synth_sub"], o["hs_synth_stats"] = sub(p2, step_lat), stats(p2)
+    o["hs_synth_idx_hist"] = np.bincount(
+        net.gaussian_conditional.build_indexes(p2.chunk(2, 1)[0]).reshape(-1).numpy(), minlength=64)
     # decoder given a synthetic, regenerable y_hat (independent of round() flips)
     t0 = time.time()
     x_hat = net.decode_latent(yhat_synth)
@@ -231,6 +239,11 @@ def run_e2e(net, x, yhat_synth, step_lat, step_img, tag):
 def synth_yhat(latent, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.round(2.0 * torch.randn(1, latent, 72, 144, generator=g)) + torch.randn(1, latent, 72, 144, generator=g)
+
+
+def synth_zhat(cz, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.round(3.0 * torch.randn(1, cz, 18, 36, generator=g))
 
 
 def stage_thin():
@@ -251,9 +264,39 @@ def stage_full():
     print("full done")
 
 
+def stage_fp64(which="full"):
+    """The reference in float64 on the same weights / inputs: calibrates the fp32 noise floor
+    (how far the reference's OWN fp32 path is from exact arithmetic).  ~6 min, ~40 GB for
+    the 268 model."""
+    if which == "full":
+        net, cin, lat, sl, si = VAEformer(268).eval(), 268, 256, 499, 99991
+    else:
+        net, cin, lat, sl, si = build_thin(), 8, 16, 37, 1009
+    load_synth(net, seed=7)
+    net = net.double()
+    x = synth.synth_frame(cin, seed=2).unsqueeze(0).double()
+    o = {}
+    t0 = time.time()
+    moments = net.quant_conv(net.g_a(x))
+    y = moments[:, : moments.shape[1] // 2]
+    print(which, "fp64 g_a", time.time() - t0)
+    o["y_sub"] = sub(y, sl)
+    z = net.h_a(y)
+    o["z_sub"] = sub(z, 13)
+    zs = synth_zhat(z.shape[1], 6).double() + net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+    o["hs_synth_sub"] = sub(net.h_s(zs), sl)
+    t0 = time.time()
+    x_hat = net.decode_latent(synth_yhat(lat, 5).double())
+    print(which, "fp64 g_s", time.time() - t0)
+    o["xhat_sub"] = sub(x_hat, si)
+    np.savez_compressed(os.path.join(HERE, f"{'full268' if which == 'full' else 'thin'}_fp64.npz"), **o)
+    print(which, "fp64 done")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", nargs="+", default=["small", "thin"])
     a = ap.parse_args()
     for s in a.stage:
-        dict(small=stage_small, thin=stage_thin, full=stage_full)[s]()
+        dict(small=stage_small, thin=stage_thin, full=stage_full, thin64=lambda: stage_fp64("thin"),
+             full64=lambda: stage_fp64("full"))[s]()

@@ -1,0 +1,45 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol that
+include/cra5_amd.h declares (no device compute is called here)."""
+import ctypes
+import os
+import re
+
+from cra5_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "cra5_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cra5_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_table_agree():
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m cra5_amd.build`"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    assert _lib.lib().cra5_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Launchers validate arguments before touching the device: bad calls return
+    CRA5_ERR_ARG (-7) even on a box with no GPU."""
+    L = _lib.lib()
+    assert L.cra5_gemm_nt_f32(None, 0, None, 0, None, 0, None, None, 0, 1, 1, 4, 0, None) == -7
+    assert L.cra5_layernorm_f32(None, 0, None, None, None, 0, 1, 3, 1e-6, None) == -7
+    assert L.cra5_window_attention_f32(None, None, None, 64, 1, 1, 1, 1, 1, 1.0, None) == -7
+    assert L.cra5_pmf_to_quantized_cdf(None, 0, 16, None) == -7
+
+
+def test_no_cuda_shims_or_dual_paths_in_sources():
+    csrc = os.path.join(ROOT, "cra5_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")):
+            s = open(os.path.join(csrc, f)).read()
+            assert "__HIP_PLATFORM_AMD__" not in s and "cuda_runtime" not in s and "hipify" not in s.lower()

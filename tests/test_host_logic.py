@@ -1,0 +1,151 @@
+"""Host-side logic of the drop-in surface (no GPU): zoo entry point, state-dict layout,
+block pattern, CDF tables, `.bin` container, API plumbing, loud failure without a GPU."""
+import io
+import json
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from cra5_amd import binfmt, synth
+from cra5_amd.entropy import EntropyBottleneck, GaussianConditional, get_scale_table
+from cra5_amd.vaeformer import VAEformer, block_windows, config_for
+from cra5_amd.zoo import load_pretrained, rename_key, vaeformer_pretrained
+
+
+def test_zoo_errors_match_reference():
+    """zoo/image.py:315-319, 281-282, 290 of the reference."""
+    with pytest.raises(ValueError, match="Invalid metric"):
+        vaeformer_pretrained(268, metric="psnr")
+    with pytest.raises(ValueError, match="Invalid quality"):
+        vaeformer_pretrained(0)
+    with pytest.raises(ValueError, match="Invalid quality value"):
+        vaeformer_pretrained(3)
+    with pytest.raises(RuntimeError, match="Pre-trained model not yet available"):
+        vaeformer_pretrained(268, pretrained=True)
+
+
+def test_rename_key():
+    assert rename_key("module.entropy_bottleneck._biases.2") == "entropy_bottleneck._bias2"
+    assert rename_key("entropy_bottleneck._matrices.0") == "entropy_bottleneck._matrix0"
+    assert rename_key("entropy_bottleneck._factors.3") == "entropy_bottleneck._factor3"
+    assert rename_key("g_a.blocks.0.norm1.weight") == "g_a.blocks.0.norm1.weight"
+    assert load_pretrained({"module.x": 1}) == {"x": 1}
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    keys = json.load(open(f"{golden_dir}/state_keys.json"))
+    thin = VAEformer(0, **synth.thin_model_kwargs())
+    assert {k: list(v.shape) for k, v in thin.state_dict().items()} == keys["thin"]
+    assert list(thin.state_dict()) == list(keys["thin"])  # same ORDER too
+    cfg = config_for(268)
+    assert (cfg["embed_dim"], cfg["depth"], cfg["num_heads"], cfg["latent_dim"]) == (1024, 24, 16, 256)
+    assert (cfg["h_embed_dim"], cfg["h_depth"], cfg["h_num_heads"], cfg["z_dim"]) == (360, 8, 5, 256)
+
+
+def test_block_pattern():
+    """SURVEY.md appendix A1 (probe-verified in the reference)."""
+    enc = block_windows(0, 12, 4, [(24, 24), (12, 48), (48, 12)])
+    assert enc == [(24, 24), (12, 48), (48, 12), None] * 3
+    dec = block_windows(12, 24, 4, [(24, 24), (12, 48), (48, 12)])
+    assert dec == [(24, 24), (12, 48), (48, 12), None] * 3
+    thin = VAEformer(0, **synth.thin_model_kwargs())
+    assert [b.window for b in thin.g_a.blocks] == [(24, 24), (12, 48), (48, 12), None, None]
+    assert [b.window for b in thin.g_s.blocks] == [(24, 24), (12, 48), (48, 12), None]
+    assert all(b.window is None for b in thin.h_a.blocks) and len(thin.h_s.blocks) == 2
+
+
+def test_from_state_dict_and_buffer_resize():
+    """vaeformer.py:168-185 + models/base.py:69-89: `backbone.` prefix stripped,
+    kl_loss.logvar dropped, empty CDF buffers resized to the checkpoint's."""
+    thin = VAEformer(0, **synth.thin_model_kwargs())
+    synth.load_synthetic(thin, seed=1)
+    sd = thin.state_dict()
+    other = VAEformer(0, **synth.thin_model_kwargs())
+    assert other.gaussian_conditional._quantized_cdf.numel() == 0
+    with pytest.raises(ValueError, match="Uninitialized CDFs"):
+        other.gaussian_conditional._check()
+    other.load_state_dict(sd)
+    assert torch.equal(other.gaussian_conditional._quantized_cdf, thin.gaussian_conditional._quantized_cdf)
+    assert torch.equal(other.entropy_bottleneck._offset, thin.entropy_bottleneck._offset)
+
+
+def test_tables_match_reference(golden_dir):
+    g = np.load(f"{golden_dir}/tables_default.npz")
+    gc = GaussianConditional(None)
+    assert gc.update_scale_table(get_scale_table(), force=True)
+    assert not gc.update_scale_table(get_scale_table())  # already initialised, no force
+    assert np.array_equal(gc._quantized_cdf.numpy(), g["gc_cdf"])
+    assert np.array_equal(gc._cdf_length.numpy(), g["gc_len"]) and np.array_equal(gc._offset.numpy(), g["gc_off"])
+    thin = VAEformer(0, **synth.thin_model_kwargs())
+    synth.load_synthetic(thin, seed=7)
+    eb = thin.entropy_bottleneck
+    assert np.array_equal(eb._quantized_cdf.numpy(), g["eb_cdf"])
+    assert np.array_equal(eb._cdf_length.numpy(), g["eb_len"]) and np.array_equal(eb._offset.numpy(), g["eb_off"])
+    with pytest.raises(ValueError):
+        GaussianConditional([3.0, 1.0])
+    with pytest.raises(ValueError):
+        GaussianConditional("x")
+
+
+def test_bin_container_byte_layout():
+    """cra5_api.py:108-117 / api/utils.py:10-34: big-endian uint32 zH, zW, n, then len+bytes."""
+    blob = binfmt.pack_bin([[b"\x01\x02\x03\x04YYYY"], [b"ZZ"]], (18, 36))
+    expect = struct.pack(">III", 18, 36, 2) + struct.pack(">I", 8) + b"\x01\x02\x03\x04YYYY" + struct.pack(">I", 2) + b"ZZ"
+    assert blob == expect
+    strings, shape = binfmt.unpack_bin(blob)
+    assert strings == [[b"\x01\x02\x03\x04YYYY"], [b"ZZ"]] and shape == (18, 36)
+    f = io.BytesIO()
+    assert binfmt.write_uints(f, (1, 2)) == 8 and binfmt.write_bytes(f, b"abc") == 3
+    f.seek(0)
+    assert binfmt.read_uints(f, 2) == (1, 2) and binfmt.read_bytes(f, 3) == b"abc"
+
+
+def test_compute_fails_loudly_without_gpu():
+    thin = VAEformer(0, **synth.thin_model_kwargs())
+    x = torch.zeros(1, 8, 721, 1440)
+    for call in (lambda: thin.compress(x), lambda: thin.encode_latent(x), lambda: thin(x),
+                 lambda: thin.decode_latent(torch.zeros(1, 16, 72, 144)),
+                 lambda: thin.decompress([[b""], [b""]], (18, 36))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+    from cra5_amd import ops
+    with pytest.raises(RuntimeError, match="non-GPU tensor"):
+        ops.gemm_nt(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_api_host_plumbing(tmp_path):
+    """Channel order, mean/std lookup, normalise round trip (cra5_api.py:228-271)."""
+    from cra5_amd.api import cra5_api
+    thin = VAEformer(0, **synth.thin_model_kwargs())
+    api = cra5_api(local_root=str(tmp_path), device="cpu", weights=thin)
+    assert len(api.channels_to_vname) == 268 and api.mean.shape == (268, 1, 1)
+    assert api.channels_to_vname[0] == "z_1000" and api.channels_to_vname[36] == "z_1"
+    assert api.channels_to_vname[37] == "q_1000" and api.channels_to_vname[259] == "v10"
+    assert api.channels_to_vname[266] == "tp" and api.channels_to_vname[267] == "msl"
+    assert api.vname_to_channels["t_850"] == 4 * 37 + 6
+    x = api.mean + api.std * torch.randn(268, 4, 5)   # physical-units data
+    n = api.normalization(x)
+    assert abs(float(n.mean())) < 0.2 and 0.8 < float(n.std()) < 1.2
+    back = api.de_normalization(n.clone())
+    assert torch.allclose(back, x, rtol=1e-5, atol=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        api.encode_to_latent("2024-06-01T00:00:00", data=torch.zeros(268, 721, 1440))
+
+
+def test_install_dropin():
+    import cra5_amd
+    cra5_amd.install_dropin()
+    from cra5.api import cra5_api  # noqa: F401
+    from cra5.models.compressai.zoo import vaeformer_pretrained as vp
+    assert vp is vaeformer_pretrained
+
+
+def test_synth_is_deterministic():
+    a = synth.synth_tensor("g_a.blocks.0.attn.qkv.weight", (6, 4), seed=7)
+    b = synth.synth_tensor("g_a.blocks.0.attn.qkv.weight", (6, 4), seed=7)
+    c = synth.synth_tensor("g_a.blocks.1.attn.qkv.weight", (6, 4), seed=7)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert synth.synth_tensor("gaussian_conditional._offset", (0,), 7) is None
+    assert torch.equal(synth.synth_frame(3, 5, 4, 6), synth.synth_frame(3, 5, 4, 6))

@@ -98,8 +98,9 @@ def test_window_attention_hd64(dev, ws):
     else:
         ref = R.attention_window(x.double(), xd, "attn", heads, H, W, ws)
     out = _attn_gpu(x[0], sd, "attn", heads, H, W, ws, dev)
-    # tolerance: fp32 matmuls + fast exp; outputs are O(0.3)
-    assert rmse(out, ref[0]) < 2e-6, rmse(out, ref[0])
+    # tolerance: the reference's own fp32 path is 2.3e-6 RMSE from fp64 on this input
+    # (outputs O(1.2)); allow 4e-6
+    assert rmse(out, ref[0]) < 4e-6, rmse(out, ref[0])
 
 
 def test_global_attention_hd72_ragged(dev):
@@ -113,7 +114,7 @@ def test_global_attention_hd72_ragged(dev):
     sd["attn.qkv.weight"] *= 3.0
     ref = R.attention_global(x.double(), {k: v.double() for k, v in sd.items()}, "attn", heads)
     out = _attn_gpu(x[0], sd, "attn", heads, H, W, None, dev)
-    assert rmse(out, ref[0]) < 2e-6
+    assert rmse(out, ref[0]) < 4e-6
 
 
 def test_attention_softmax_spike(dev):

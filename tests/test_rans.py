@@ -1,0 +1,134 @@
+"""Entropy coder: product C++ (through the C ABI) vs the oracle C restatement vs the
+independent pure-Python restatement - bit-exact streams, round trips, adversarial cases
+(escape symbols, every table, empty / 1-symbol inputs, corrupt streams)."""
+import numpy as np
+import pytest
+
+from cra5_amd import ops
+from cra5_amd._lib import Cra5Error
+from oracle import cbind, rans_py
+from oracle import torch_ref as R
+
+
+def _random_tables(rng, ncdf, L):
+    cdf = np.zeros((ncdf, L + 2), np.int32)
+    lens = np.zeros(ncdf, np.int32)
+    offs = np.zeros(ncdf, np.int32)
+    for c in range(ncdf):
+        n = int(rng.integers(2, L + 1))
+        p = rng.random(n).astype(np.float32) ** int(rng.integers(1, 6))
+        p /= p.sum()
+        q = cbind.pmf_to_cdf(p)
+        cdf[c, : n + 1] = q
+        lens[c] = n + 1
+        offs[c] = -int(rng.integers(0, n))
+    return cdf, lens, offs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_three_implementations_agree(seed):
+    rng = np.random.default_rng(seed)
+    cdf, lens, offs = _random_tables(rng, int(rng.integers(1, 9)), int(rng.integers(3, 60)))
+    n = int(rng.integers(0, 4000))
+    idx = rng.integers(0, cdf.shape[0], size=n).astype(np.int32)
+    sym = rng.integers(-80, 80, size=n).astype(np.int32)
+    if seed % 3 == 0 and n:
+        sym[:: 5] = rng.integers(-(1 << 20), 1 << 20, size=sym[::5].size)  # long escape payloads
+    a = ops.rans_encode(sym, idx, cdf, lens, offs)
+    b = cbind.rans_encode(sym, idx, cdf, lens, offs)
+    c = rans_py.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
+    assert a == b == c
+    assert len(a) % 4 == 0 and len(a) >= 8
+    assert np.array_equal(ops.rans_decode(a, idx, cdf, lens, offs), sym)
+    assert np.array_equal(cbind.rans_decode(a, idx, cdf, lens, offs).numpy(), sym)
+    assert rans_py.RansDecoder().decode_with_indexes(a, idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist()) == sym.tolist()
+
+
+def test_empty_and_single_symbol():
+    rng = np.random.default_rng(1)
+    cdf, lens, offs = _random_tables(rng, 2, 10)
+    e = np.zeros(0, np.int32)
+    s = ops.rans_encode(e, e, cdf, lens, offs)
+    assert s == cbind.rans_encode(e, e, cdf, lens, offs) and len(s) == 8  # just the flushed state
+    assert ops.rans_decode(s, e, cdf, lens, offs).size == 0
+    one = np.array([0], np.int32)
+    s = ops.rans_encode(one, one, cdf, lens, offs)
+    assert s == cbind.rans_encode(one, one, cdf, lens, offs)
+    assert ops.rans_decode(s, one, cdf, lens, offs).tolist() == [0]
+
+
+def test_full_gaussian_tables_all_indexes():
+    """Every one of the 64 default GC tables, symbols at and beyond both tails."""
+    cdf, ln, off = [t.numpy() for t in R.gc_tables(R.get_scale_table(), cbind.pmf_to_cdf)]
+    rng = np.random.default_rng(3)
+    idx = np.repeat(np.arange(64, dtype=np.int32), 200)
+    sigma = R.get_scale_table().numpy()[idx]
+    sym = np.rint(rng.standard_normal(idx.size) * sigma * 1.5).astype(np.int32)
+    sym[::50] = (-off[idx[::50]] + 3)        # just past the upper tail -> escape
+    sym[1::50] = (off[idx[1::50]] - 3)       # just past the lower tail -> escape
+    sym[2::50] = -off[idx[2::50]]            # exactly the last regular bin / escape boundary
+    a = ops.rans_encode(sym, idx, cdf, ln, off)
+    assert a == cbind.rans_encode(sym, idx, cdf, ln, off)
+    assert np.array_equal(ops.rans_decode(a, idx, cdf, ln, off), sym)
+
+
+def test_batch_api_threads():
+    import ctypes
+    from cra5_amd._lib import lib
+    rng = np.random.default_rng(5)
+    cdf, lens, offs = _random_tables(rng, 4, 30)
+    streams = []
+    for i in range(6):
+        n = int(rng.integers(100, 5000))
+        streams.append((rng.integers(-40, 40, size=n).astype(np.int32), rng.integers(0, 4, size=n).astype(np.int32)))
+    ns = len(streams)
+    VP = ctypes.c_void_p
+    sym = (VP * ns)(*[s.ctypes.data for s, _ in streams])
+    idx = (VP * ns)(*[i.ctypes.data for _, i in streams])
+    n = (ctypes.c_size_t * ns)(*[s.size for s, _ in streams])
+    cd = (VP * ns)(*[cdf.ctypes.data] * ns)
+    ncd = (ctypes.c_int * ns)(*[cdf.shape[0]] * ns)
+    st = (ctypes.c_int * ns)(*[cdf.shape[1]] * ns)
+    ln = (VP * ns)(*[lens.ctypes.data] * ns)
+    of = (VP * ns)(*[offs.ctypes.data] * ns)
+    out = (VP * ns)()
+    olen = (ctypes.c_size_t * ns)()
+    rc = (ctypes.c_int * ns)()
+    assert lib().cra5_rans_encode_batch(ns, sym, idx, n, cd, ncd, st, ln, of, out, olen, rc, 4) == 0
+    blobs = [ctypes.string_at(out[i], olen[i]) for i in range(ns)]
+    for i, (s, ix) in enumerate(streams):
+        assert blobs[i] == ops.rans_encode(s, ix, cdf, lens, offs)
+    dec = [np.empty(s.size, np.int32) for s, _ in streams]
+    enc = (VP * ns)(*[ctypes.cast(ctypes.c_char_p(b), VP).value for b in blobs])
+    elen = (ctypes.c_size_t * ns)(*[len(b) for b in blobs])
+    dout = (VP * ns)(*[d.ctypes.data for d in dec])
+    assert lib().cra5_rans_decode_batch(ns, enc, elen, idx, n, cd, ncd, st, ln, of, dout, rc, 3) == 0
+    for d, (s, _) in zip(dec, streams):
+        assert np.array_equal(d, s)
+    for i in range(ns):
+        lib().cra5_free(out[i])
+
+
+def test_errors_are_codes_not_ub():
+    rng = np.random.default_rng(2)
+    cdf, lens, offs = _random_tables(rng, 2, 10)
+    sym = np.zeros(4, np.int32)
+    with pytest.raises(Cra5Error):
+        ops.rans_encode(sym, np.array([0, 1, 2, 0], np.int32), cdf, lens, offs)  # index out of range
+    good_idx = np.zeros(4, np.int32)
+    s = ops.rans_encode(sym, good_idx, cdf, lens, offs)
+    with pytest.raises(Cra5Error):
+        ops.rans_decode(s[:4], good_idx, cdf, lens, offs)  # truncated
+    with pytest.raises(ValueError):
+        ops.rans_encode(sym, good_idx[:3], cdf, lens, offs)
+
+
+def test_product_pmf_to_cdf_matches_reference(golden_dir):
+    import json
+    g = json.load(open(f"{golden_dir}/pmf_cdf.json"))
+    for c in g["cases"]:
+        assert ops.pmf_to_quantized_cdf(np.array(c["pmf"], dtype=np.float32), c["precision"]).tolist() == c["cdf"]
+    for e in g["errors"]:
+        if e["raises"]:
+            with pytest.raises(ValueError):  # std::domain_error -> ValueError in the reference binding
+                ops.pmf_to_quantized_cdf(np.array([float(v) for v in e["pmf"]], dtype=np.float32))
