@@ -135,7 +135,8 @@ class cra5_api:
         """normalise + g_a + quant_conv for one physical-units frame (fused normalisation)."""
         with torch.no_grad():
             self.net._require_gpu()
-            return self.net._encode_y_frame(frame, mean=self._mean_flat, std=self._std_flat)
+            with self.net._gpu_phase():
+                return self.net._encode_y_frame(frame, mean=self._mean_flat, std=self._std_flat)
 
     def encode_to_latent(self, time_stamp=None, save_root=None, latent_type='float', data=None):
         """cra5_api.py:53-71."""
@@ -145,7 +146,8 @@ class cra5_api:
             if latent_type == 'float':
                 return y.unsqueeze(0)
             if latent_type == 'quantized':
-                s = self.net._latent_side_frame(y)
+                with self.net._gpu_phase():
+                    s = self.net._latent_side_frame(y)
                 return s["y_hat"].reshape(y.shape).unsqueeze(0)
 
     def latent_to_bin(self, y, save_root=None):
@@ -164,7 +166,8 @@ class cra5_api:
             if return_format == 'latent':
                 return y.unsqueeze(0)
             if return_format == 'quantized':
-                s = self.net._latent_side_frame(y)
+                with self.net._gpu_phase():
+                    s = self.net._latent_side_frame(y)
                 return s["y_hat"].reshape(y.shape).unsqueeze(0)
             output = self.net.compress_from_latent(y.unsqueeze(0))
         st3 = time.time()
@@ -211,7 +214,8 @@ class cra5_api:
                 x_hat = self.net.decode_latent(y_hat)
             elif return_format in ('de_normalized', 'de_normlized'):
                 # fused de-normalisation in the overlap-add store
-                x_hat = self.net._decode_frame(y_hat[0], mean=self._mean_flat, std=self._std_flat)
+                with self.net._gpu_phase():
+                    x_hat = self.net._decode_frame(y_hat[0], mean=self._mean_flat, std=self._std_flat)
             else:
                 raise ValueError(f"unknown return_format {return_format!r}")
         torch.cuda.synchronize()

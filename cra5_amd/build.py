@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcra5_amd.so")
-SOURCES = ["host_entropy.cpp", "gemm_f32.hip", "attention_f32.hip", "elementwise.hip"]
+SOURCES = ["host_entropy.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "attention_f32.hip", "elementwise.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -20,7 +20,8 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "cra5_amd.h")]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "cra5_amd.h"),
+                                                       os.path.join(CSRC, "split.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -32,7 +33,8 @@ def build(force=False, verbose=False):
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "cra5_amd.h"))):
+                os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "..", "include", "cra5_amd.h")),
+                os.path.getmtime(os.path.join(CSRC, "split.h"))):
             cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
             if s.endswith(".cpp"):
                 cmd.insert(1, "-x")

@@ -34,6 +34,7 @@
 #include <math.h>
 
 #include "../../include/cra5_amd.h"
+#include "split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -59,8 +60,8 @@ __device__ __forceinline__ int token_of(const WinGeom &g, int wr, int wc, int t)
 
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void window_attention_f32_kernel(
-    const float *__restrict__ qkv, const float *__restrict__ pad_row, float *__restrict__ out, int C,
-    int heads, WinGeom g, int q_tiles, float scale) {
+    const float *__restrict__ qkv, const float *__restrict__ pad_row, float *__restrict__ out,
+    unsigned short *__restrict__ out_s, int Kp, int C, int heads, WinGeom g, int q_tiles, float scale) {
   constexpr int HH = HD / 2;                 // d-range per MFMA k-slot
   constexpr int DT = (HD + 31) / 32;         // 32-wide output tiles over the head dim
   constexpr int KS = HD + 4;                 // K LDS row stride (floats)
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(NW * 64) void window_attention_f32_kernel(
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);  // merge the two key halves
   if (q_tok >= 0) {
     const float inv = 1.0f / l_tot;
-    float *orow = out + (size_t)q_tok * C + hoff;
+    float *orow = out ? out + (size_t)q_tok * C + hoff : nullptr;
+    unsigned short *srow = out_s ? out_s + (size_t)q_tok * 2 * Kp : nullptr;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -243,15 +245,16 @@ __global__ __launch_bounds__(NW * 64) void window_attention_f32_kernel(
           v.y = o[t][4 * gq + 1] * inv;
           v.z = o[t][4 * gq + 2] * inv;
           v.w = o[t][4 * gq + 3] * inv;
-          *reinterpret_cast<float4 *>(orow + d) = v;
+          if (orow) *reinterpret_cast<float4 *>(orow + d) = v;
+          if (srow) cra5_store_split4(srow, hoff + d, v.x, v.y, v.z, v.w);
         }
       }
   }
 }
 
 template <int HD, int NW>
-int launch(const float *qkv, const float *pad_row, float *out, int C, int heads, int H, int W, int wh,
-           int ww, float scale, hipStream_t st) {
+int launch(const float *qkv, const float *pad_row, float *out, unsigned short *out_s, int Kp, int C, int heads,
+           int H, int W, int wh, int ww, float scale, hipStream_t st) {
   WinGeom g;
   g.H = H;
   g.W = W;
@@ -262,17 +265,20 @@ int launch(const float *qkv, const float *pad_row, float *out, int C, int heads,
   const int L = wh * ww;
   const int q_tiles = (L + NW * 32 - 1) / (NW * 32);
   dim3 grid(q_tiles * nwr * g.nwc * heads), block(NW * 64);
-  hipLaunchKernelGGL((window_attention_f32_kernel<HD, NW>), grid, block, 0, st, qkv, pad_row, out, C, heads, g,
-                     q_tiles, scale);
+  hipLaunchKernelGGL((window_attention_f32_kernel<HD, NW>), grid, block, 0, st, qkv, pad_row, out, out_s, Kp,
+                     C, heads, g, q_tiles, scale);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-extern "C" int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out, int C,
-                                         int heads, int H, int W, int wh, int ww, float scale,
-                                         void *stream) {
-  if (!qkv || !pad_row || !out || heads <= 0 || C % heads) return CRA5_ERR_ARG;
+extern "C" int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out, uint16_t *out_split,
+                                         int split_kp, int C, int heads, int H, int W, int wh, int ww,
+                                         float scale, void *stream) {
+  if (!qkv || !pad_row || (!out && !out_split) || heads <= 0 || C % heads) return CRA5_ERR_ARG;
+  if (out_split && (split_kp < C || split_kp % 32)) return CRA5_ERR_ARG;
+  unsigned short *out_s = out_split;
+  const int Kp = split_kp;
   if (wh <= 0 || ww <= 0 || H <= 0 || W <= 0) return CRA5_ERR_ARG;
   if ((C & 3) || ((uintptr_t)qkv & 15) || ((uintptr_t)pad_row & 15) || ((uintptr_t)out & 15)) return CRA5_ERR_ARG;
   const int hd = C / heads;
@@ -281,9 +287,9 @@ extern "C" int cra5_window_attention_f32(const float *qkv, const float *pad_row,
   if (hd == 64) {
     // 576-token windows: 192 queries per block (3 blocks per window-head, no ragged tail);
     // long sequences: 128 queries per block for finer load balance.
-    if (L % 192 == 0 && L <= 1152) return launch<64, 6>(qkv, pad_row, out, C, heads, H, W, wh, ww, scale, st);
-    return launch<64, 4>(qkv, pad_row, out, C, heads, H, W, wh, ww, scale, st);
+    if (L % 192 == 0 && L <= 1152) return launch<64, 6>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
+    return launch<64, 4>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
   }
-  if (hd == 72) return launch<72, 4>(qkv, pad_row, out, C, heads, H, W, wh, ww, scale, st);
+  if (hd == 72) return launch<72, 4>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
   return CRA5_ERR_ARG;
 }

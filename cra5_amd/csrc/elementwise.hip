@@ -7,6 +7,7 @@
 #include <math.h>
 
 #include "../../include/cra5_amd.h"
+#include "split.h"
 
 namespace {
 
@@ -24,7 +25,8 @@ template <int V4>  // float4 per lane (D <= V4 * 256)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int ldx,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float *__restrict__ y,
-                                                        int ldy, int rows, int D, float eps) {
+                                                        int ldy, unsigned short *__restrict__ ys, int Kp, int rows,
+                                                        int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
   }
   const float var = wave_sum(q) / (float)D;
   const float rstd = 1.0f / sqrtf(var + eps);
-  float *yr = y + (size_t)row * ldy;
+  float *yr = y ? y + (size_t)row * ldy : nullptr;
 #pragma unroll
   for (int i = 0; i < V4; ++i) {
     const int c = (i * 64 + lane) * 4;
@@ -62,9 +64,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      *reinterpret_cast<float4 *>(yr + c) = o;
+      if (y) *reinterpret_cast<float4 *>(yr + c) = o;
+      if (ys) cra5_store_split4(ys + (size_t)row * 2 * Kp, c, o.x, o.y, o.z, o.w);
     }
   }
+  if (ys)  // zero the K padding of the split row (D..Kp)
+    for (int c = D + lane; c < Kp; c += 64) cra5_store_split(ys + (size_t)row * 2 * Kp, c, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -73,8 +78,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                      const float *__restrict__ stdv, float *__restrict__ cols,
-                                                     int C, int H, int W, int kh, int kw, int sh, int sw,
-                                                     int Hp, int Wp, int ldk) {
+                                                     unsigned short *__restrict__ cols_s, int C, int H, int W,
+                                                     int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk) {
   const int K = C * kh * kw;
   const size_t total = (size_t)Hp * Wp * K;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -86,7 +91,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
     const int i = ij / kw, j = ij - i * kw;
     float v = x[((size_t)c * H + (ph * sh + i)) * W + (pw * sw + j)];
     if (mean) v = (v - mean[c]) / stdv[c];
-    cols[(size_t)tok * ldk + k] = v;
+    if (cols) cols[(size_t)tok * ldk + k] = v;
+    if (cols_s) cra5_store_split(cols_s + (size_t)tok * 2 * ldk, k, v);
   }
 }
 
@@ -302,27 +308,32 @@ inline int grid_for(size_t n, int block = 256) {
 
 extern "C" {
 
-int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float *beta, float *y, int ldy, int rows,
-                       int D, float eps, void *stream) {
-  if (!x || !gamma || !beta || !y || rows <= 0 || D <= 0 || (D & 3) || (ldx & 3) || (ldy & 3) || D > 2048)
+int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float *beta, float *y, int ldy,
+                       uint16_t *y_split, int split_kp, int rows, int D, float eps, void *stream) {
+  if (!x || !gamma || !beta || (!y && !y_split) || rows <= 0 || D <= 0 || (D & 3) || (ldx & 3) || D > 2048)
     return CRA5_ERR_ARG;
+  if (y && (ldy & 3)) return CRA5_ERR_ARG;
+  if (y_split && (split_kp < D || split_kp % 32)) return CRA5_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4), block(256);
-  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
-  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
-  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+#define CRA5_LN(V) hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, y_split, split_kp, rows, D, eps)
+  if (D <= 256) CRA5_LN(1);
+  else if (D <= 512) CRA5_LN(2);
+  else if (D <= 1024) CRA5_LN(4);
+  else CRA5_LN(8);
+#undef CRA5_LN
   return (int)hipGetLastError();
 }
 
-int cra5_im2col_f32(const float *x, const float *mean, const float *stdv, float *cols, int C, int H, int W, int kh,
-                    int kw, int sh, int sw, int Hp, int Wp, int ldk, void *stream) {
-  if (!x || !cols || C <= 0 || ldk < C * kh * kw) return CRA5_ERR_ARG;
+int cra5_im2col_f32(const float *x, const float *mean, const float *stdv, float *cols, uint16_t *cols_split, int C,
+                    int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk, void *stream) {
+  if (!x || (!cols && !cols_split) || C <= 0 || ldk < C * kh * kw) return CRA5_ERR_ARG;
+  if (cols_split && (ldk % 32)) return CRA5_ERR_ARG;
   if ((Hp - 1) * sh + kh > H || (Wp - 1) * sw + kw > W) return CRA5_ERR_ARG;
   if ((mean == nullptr) != (stdv == nullptr)) return CRA5_ERR_ARG;
   const size_t total = (size_t)Hp * Wp * C * kh * kw;
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, cols, C,
-                     H, W, kh, kw, sh, sw, Hp, Wp, ldk);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, cols,
+                     cols_split, C, H, W, kh, kw, sh, sw, Hp, Wp, ldk);
   return (int)hipGetLastError();
 }
 

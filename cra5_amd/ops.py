@@ -68,7 +68,7 @@ def _dev(*ts):
         if not t.is_cuda:
             raise RuntimeError("cra5_amd device op called with a non-GPU tensor: the HIP path is the only path "
                                "(the CPU restatement lives in oracle/ and is test infrastructure)")
-        if t.dtype not in (torch.float32, torch.int32):
+        if t.dtype not in (torch.float32, torch.int32, torch.int16):
             raise TypeError(f"unsupported dtype {t.dtype}")
 
 
@@ -99,48 +99,140 @@ def gemm_nt(a, w, bias=None, res=None, gelu=False, out=None):
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-6, out=None):
-    _dev(x, gamma, beta, out)
-    rows, D = x.shape
+class SplitMat:
+    """A [rows, K] fp32 matrix in the split-f16 layout of csrc/gemm_split_f16.hip: `data` is a
+    uint16 tensor [rows, 2*Kp] (128-byte chunks of 32 hi | 32 lo halves), Kp = K rounded up to
+    32 (zero padded), value = (hi + lo) * scale_inv."""
+
+    __slots__ = ("data", "rows", "K", "Kp", "scale_inv")
+
+    def __init__(self, data, rows, K, Kp, scale_inv=1.0):
+        self.data, self.rows, self.K, self.Kp, self.scale_inv = data, rows, K, Kp, scale_inv
+
+    @staticmethod
+    def empty(rows, K, device, zero=False):
+        Kp = (K + 31) // 32 * 32
+        # int16 storage (torch has no uint16 arithmetic; only the bytes matter)
+        data = (torch.zeros if zero else torch.empty)((rows, 2 * Kp), device=device, dtype=torch.int16)
+        return SplitMat(data, rows, K, Kp)
+
+    def to_float(self):
+        """Reconstruct the fp32 values (tests / debugging)."""
+        h = self.data.view(torch.float16).view(self.rows, self.Kp // 32, 2, 32).float()
+        return ((h[:, :, 0] + h[:, :, 1]).reshape(self.rows, self.Kp)[:, : self.K]) * self.scale_inv
+
+
+def _devs(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cra5_amd device op called with a non-GPU tensor: the HIP path is the only path")
+
+
+def split_f16(x, scale_pow2=None, out=None):
+    """fp32 [rows, K] (row-strided ok) -> SplitMat.  scale_pow2: None = 1.0; 'auto' = the
+    power of two that brings max|x| into [2^12, 2^13) (weights)."""
+    _dev(x)
+    rows, K = x.shape
+    scale = 1.0
+    if scale_pow2 == "auto":
+        amax = float(x.abs().max())
+        if amax > 0 and amax == amax and amax != float("inf"):
+            import math
+            scale = 2.0 ** (12 - math.floor(math.log2(amax)))
+    elif scale_pow2 is not None:
+        scale = float(scale_pow2)
     if out is None:
-        out = torch.empty((rows, D), device=x.device, dtype=torch.float32)
-    check(lib().cra5_layernorm_f32(_p(x), _row_stride(x), _p(gamma), _p(beta), _p(out), _row_stride(out), rows, D,
-                                   float(eps), _stream()), "cra5_layernorm_f32")
+        out = SplitMat.empty(rows, K, x.device)
+    check(lib().cra5_split_f16(_p(x), _row_stride(x), _p(out.data), rows, K, out.Kp, scale, _stream()),
+          "cra5_split_f16")
+    out.scale_inv = 1.0 / scale
     return out
 
 
-def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None):
-    """qkv: [H*W, 3C] contiguous; returns [H*W, C]."""
+def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True):
+    """epi(a @ w^T) with a, w SplitMat (same K).  out: fp32 [M, N] (row-strided ok) unless
+    want_f32=False; out_split: SplitMat [M, N] to receive the split-f16 result."""
+    _devs(a.data, w.data)
+    _dev(bias, res, out)
+    M, N = a.rows, w.rows
+    assert a.Kp == w.Kp and a.K == w.K, (a.K, w.K)
+    assert a.scale_inv == 1.0, "activations are split unscaled"
+    if out is None and want_f32:
+        out = torch.empty((M, N), device=a.data.device, dtype=torch.float32)
+    if out_split is not None:
+        assert out_split.rows == M and out_split.K == N
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
+    ev = TIMER.start() if TIMER is not None else None
+    check(lib().cra5_gemm_nt_split(_p(a.data), _p(w.data), _p(out), _row_stride(out) if out is not None else 0,
+                                   _p(out_split.data) if out_split is not None else None,
+                                   out_split.Kp if out_split is not None else 0, _p(bias), _p(res),
+                                   _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv), flags,
+                                   _stream()), "cra5_gemm_nt_split")
+    if ev is not None:
+        TIMER.stop("gemm_nt_split", ev, 2.0 * M * N * a.K)
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-6, out=None, out_split=None, want_f32=True):
+    _dev(x, gamma, beta, out)
+    rows, D = x.shape
+    if out is None and want_f32:
+        out = torch.empty((rows, D), device=x.device, dtype=torch.float32)
+    if out_split is not None:
+        assert out_split.rows == rows and out_split.K == D
+    check(lib().cra5_layernorm_f32(_p(x), _row_stride(x), _p(gamma), _p(beta), _p(out),
+                                   _row_stride(out) if out is not None else 0,
+                                   _p(out_split.data) if out_split is not None else None,
+                                   out_split.Kp if out_split is not None else 0, rows, D, float(eps), _stream()),
+          "cra5_layernorm_f32")
+    return out if out is not None else out_split
+
+
+def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None, out_split=None, want_f32=True):
+    """qkv: [H*W, 3C] contiguous; returns [H*W, C] (fp32) and/or fills out_split (SplitMat,
+    whose pad columns must already be zero)."""
     _dev(qkv, pad_row, out)
     N, C3 = qkv.shape
     C = C3 // 3
     assert N == H * W and qkv.is_contiguous() and pad_row.numel() == C3
-    if out is None:
+    if out is None and want_f32:
         out = torch.empty((N, C), device=qkv.device, dtype=torch.float32)
-    assert out.is_contiguous()
+    assert out is None or out.is_contiguous()
+    if out_split is not None:
+        assert out_split.rows == N and out_split.K == C
     scale = float((C // heads) ** -0.5)
     ev = TIMER.start() if TIMER is not None else None
-    check(lib().cra5_window_attention_f32(_p(qkv), _p(pad_row), _p(out), C, heads, H, W, wh, ww, scale, _stream()),
-          "cra5_window_attention_f32")
+    check(lib().cra5_window_attention_f32(_p(qkv), _p(pad_row), _p(out),
+                                          _p(out_split.data) if out_split is not None else None,
+                                          out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
+                                          scale, _stream()), "cra5_window_attention_f32")
     if ev is not None:
         # algorithmic flops: real (unpadded) queries x all keys of their window, QK^T + PV
         L = wh * ww
         TIMER.stop("window_attention_f32", ev, 4.0 * N * L * C)
-    return out
+    return out if out is not None else out_split
 
 
-def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None):
-    """x: [C,H,W] -> cols [Hp*Wp, ldk] (column (c*kh+i)*kw+j); pad columns are zero."""
+def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split=None):
+    """x: [C,H,W] -> cols [Hp*Wp, ldk] (column (c*kh+i)*kw+j); pad columns are zero.  With
+    out_split (a ZERO-initialised SplitMat [Hp*Wp, C*kh*kw]) the split-f16 form is written
+    instead of the fp32 one."""
     _dev(x, mean, std, out)
     C, H, W = x.shape
     Hp, Wp = (H - kh) // sh + 1, (W - kw) // sw + 1
     K = C * kh * kw
+    assert x.is_contiguous()
+    if out_split is not None:
+        assert out_split.rows == Hp * Wp and out_split.K == K
+        check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), None, _p(out_split.data), C, H, W, kh, kw, sh, sw, Hp,
+                                    Wp, out_split.Kp, _stream()), "cra5_im2col_f32")
+        return out_split
     ldk = ldk or K
     if out is None:
         out = torch.zeros((Hp * Wp, ldk), device=x.device, dtype=torch.float32)
-    assert x.is_contiguous() and out.is_contiguous() and out.shape[1] == ldk
-    check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), _p(out), C, H, W, kh, kw, sh, sw, Hp, Wp, ldk, _stream()),
-          "cra5_im2col_f32")
+    assert out.is_contiguous() and out.shape[1] == ldk
+    check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), _p(out), None, C, H, W, kh, kw, sh, sw, Hp, Wp, ldk,
+                                _stream()), "cra5_im2col_f32")
     return out
 
 

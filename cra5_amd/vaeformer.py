@@ -17,7 +17,10 @@ Reference behaviour kept on purpose:
     stream (lossless coder), so the encode side skips the redundant rANS decode.
 There is no CPU path: on a non-GPU device every compute method raises.
 """
+import contextlib
 import math
+import os
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -254,8 +257,13 @@ class VAEformer(nn.Module):
         self.h_s = _Decoder(hd, hh, [None] * (cfg['h_depth'] - n_h),
                             _Linear(hd, 2 * cfg['h_in_chans'] * zh * zw, bias=False), cfg['z_dim'])
         self.gaussian_conditional = GaussianConditional(None)
+        self.gemm_mode = os.environ.get("CRA5_GEMM", "split")
+        if self.gemm_mode not in ("split", "f32"):
+            raise ValueError("CRA5_GEMM must be 'split' or 'f32'")
         self._derived = {}
-        self._ws = {}
+        self._derive_lock = threading.RLock()
+        self._gpu_lock = threading.Lock()
+        self._tls = threading.local()  # per-thread workspaces: one frame pipeline per thread/stream
         self.eval()
 
     # ---- reference-compatible loading (vaeformer.py:168-185, base.py:69-89) -------------
@@ -307,12 +315,17 @@ class VAEformer(nn.Module):
                                "Move the model with .to('cuda'); the CPU restatement lives in oracle/ (tests only).")
 
     def _buf(self, name, shape, dtype=torch.float32, zero=False):
-        """Persistent workspace (allocated once per device)."""
+        """Persistent workspace, allocated once per (thread, device): concurrent frame
+        pipelines (cra5_amd/pipeline.py: one host thread + one HIP stream per in-flight
+        frame) never share activation buffers; weights are shared read-only."""
+        ws = getattr(self._tls, "ws", None)
+        if ws is None:
+            ws = self._tls.ws = {}
         key = (name, tuple(shape), dtype, str(self.device))
-        b = self._ws.get(name)
+        b = ws.get(name)
         if b is None or b[0] != key:
             t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
-            self._ws[name] = (key, t)
+            ws[name] = (key, t)
             return t
         return b[1]
 
@@ -321,46 +334,103 @@ class VAEformer(nn.Module):
         key = (src.data_ptr(), src._version, str(src.device))
         d = self._derived.get(name)
         if d is None or d[0] != key:
-            with torch.no_grad():
-                d = (key, fn(src.detach()))
-            self._derived[name] = d
+            with self._derive_lock:
+                d = self._derived.get(name)
+                if d is None or d[0] != key:
+                    with torch.no_grad():
+                        d = (key, fn(src.detach()))
+                    torch.cuda.current_stream().synchronize()  # visible to every stream
+                    self._derived[name] = d
         return d[1]
 
-    def _w_patch_embed(self):
-        """Conv2d(C -> D, k=(11,10)) as W[D][K_pad], K = C*110 zero-padded to a multiple of 32."""
-        w = self.g_a.patch_embed.proj.weight
+    # ---- GEMM engine ------------------------------------------------------------------------
+    # gemm_mode "split" (default): every projection runs on the f16 matrix cores with fp32
+    # operands split into hi/lo halves (csrc/gemm_split_f16.hip: fp32-class accuracy at ~4x the
+    # exact-f32 MFMA rate); the producers (LayerNorm, GELU epilogue, attention, patch gather)
+    # emit the split layout directly.  gemm_mode "f32": the exact v_mfma_f32_32x32x2_f32 kernel
+    # (csrc/gemm_f32.hip) - kept as the bit-for-bit-fmaf reference engine.
+    def _sbuf(self, name, rows, K, zero=False):
+        ws = getattr(self._tls, "sws", None)
+        if ws is None:
+            ws = self._tls.sws = {}
+        key = (rows, K, str(self.device))
+        b = ws.get(name)
+        if b is None or b[0] != key:
+            b = (key, ops.SplitMat.empty(rows, K, self.device, zero=zero))
+            ws[name] = b
+        return b[1]
 
-        def mk(w):
-            D = w.shape[0]
-            K = w[0].numel()
-            out = torch.zeros((D, _rup(K, 32)), device=w.device, dtype=torch.float32)
-            out[:, :K] = w.reshape(D, K)
-            return out
-        return self._derive("w_pe", w, mk)
+    def _weight2d(self, key, w):
+        """GEMM-ready [N, K] view / re-layout of a parameter (cached)."""
+        if key == "g_s.final":     # ConvTranspose2d (D, C, kh, kw) -> W[N = C*kh*kw][K = D]
+            return self._derive("w2d." + key, w, lambda w: w.reshape(w.shape[0], -1).t().contiguous())
+        return w.detach().reshape(w.shape[0], -1)
 
-    def _w_unembed(self):
-        """ConvTranspose2d(D -> C, k=(11,10)) weight (D, C, kh, kw) as W[N = C*110][K = D]."""
-        w = self.g_s.final.weight
-        return self._derive("w_ue", w, lambda w: w.reshape(w.shape[0], -1).t().contiguous())
+    def _wsplit(self, key, w):
+        """Split-f16 copy of a weight, scaled by a per-tensor power of two (cached)."""
+        return self._derive("ws." + key, w, lambda w: ops.split_f16(self._weight2d(key, w).contiguous(), "auto"))
+
+    def _wf32(self, key, w, pad32=False):
+        w2 = self._weight2d(key, w)
+        if pad32 and w2.shape[1] % 32:
+            def mk(_):
+                out = torch.zeros((w2.shape[0], _rup(w2.shape[1], 32)), device=w2.device, dtype=torch.float32)
+                out[:, : w2.shape[1]] = w2
+                return out
+            return self._derive("wp." + key, w, mk)
+        return w2
+
+    def _act(self, t, name):
+        """fp32 activation [rows, K] -> GEMM input handle for the current engine."""
+        if self.gemm_mode == "split":
+            return ops.split_f16(t, out=self._sbuf(name, t.shape[0], t.shape[1]))
+        return t
+
+    def _ln(self, x, norm, name):
+        rows, D = x.shape
+        if self.gemm_mode == "split":
+            sm = self._sbuf(name, rows, D)
+            ops.layernorm(x, norm.weight, norm.bias, 1e-6, out_split=sm, want_f32=False)
+            return sm
+        return ops.layernorm(x, norm.weight, norm.bias, 1e-6, out=self._buf(name, (rows, D)))
+
+    def _mm(self, a, key, w, bias=None, res=None, gelu=False, out=None, out_name=None):
+        """epi(a @ W^T).  `out`: fp32 destination (tensor / strided view) or None; `out_name`:
+        produce the result as the next GEMM's input (split engine: written split by the
+        epilogue, no fp32 copy; f32 engine: a named fp32 workspace)."""
+        if self.gemm_mode == "split":
+            W = self._wsplit(key, w)
+            if out_name is not None:
+                sm = self._sbuf(out_name, a.rows, W.rows)
+                ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False)
+                return sm
+            return ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out=out)
+        W = self._wf32(key, w, pad32=(a.shape[1] % 32 == 0 and self._weight2d(key, w).shape[1] != a.shape[1]))
+        if out_name is not None:
+            out = self._buf(out_name, (a.shape[0], W.shape[0]))
+        return ops.gemm_nt(a, W, bias=bias, res=res, gelu=gelu, out=out)
 
     # ---- transformer block on device -----------------------------------------------------
-    def _block(self, blk, t_in, t_out, grid):
-        """vit_nlc.py:282-287. t_in: [N, D] input; t_out: [N, D] (may be t_in, may be a strided
-        view) receives x + attn(LN(x)) + mlp(LN(.))."""
+    def _block(self, blk, pre, t_in, t_out, grid):
+        """vit_nlc.py:282-287. t_in: [N, D] fp32 residual stream; t_out: [N, D] (may be t_in, may
+        be a strided view) receives x + attn(LN(x)) + mlp(LN(.))."""
         N, D = t_in.shape
         H, W = grid
-        h = self._buf(f"h{D}", (N, D))
-        qkv = self._buf(f"qkv{D}", (N, 3 * D))
-        att = self._buf(f"att{D}", (N, D))
-        hid = self._buf(f"hid{D}", (N, 4 * D))
-        ops.layernorm(t_in, blk.norm1.weight, blk.norm1.bias, 1e-6, out=h)
-        ops.gemm_nt(h, blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out=qkv)
+        split = self.gemm_mode == "split"
+        h = self._ln(t_in, blk.norm1, f"h{D}")
+        qkv = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias,
+                       out=self._buf(f"qkv{D}", (N, 3 * D)))
         wh, ww = blk.window if blk.window is not None else (H, W)
-        ops.window_attention(qkv, blk.attn.qkv.bias, blk.heads, H, W, wh, ww, out=att)
-        ops.gemm_nt(att, blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
-        ops.layernorm(t_out, blk.norm2.weight, blk.norm2.bias, 1e-6, out=h)
-        ops.gemm_nt(h, blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias, gelu=True, out=hid)
-        ops.gemm_nt(hid, blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias, res=t_out, out=t_out)
+        if split:
+            att = self._sbuf(f"att{D}", N, D, zero=True)   # pad columns stay zero
+            ops.window_attention(qkv, blk.attn.qkv.bias, blk.heads, H, W, wh, ww, out_split=att, want_f32=False)
+        else:
+            att = ops.window_attention(qkv, blk.attn.qkv.bias, blk.heads, H, W, wh, ww,
+                                       out=self._buf(f"att{D}", (N, D)))
+        self._mm(att, pre + ".attn.proj", blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
+        h = self._ln(t_out, blk.norm2, f"h{D}")
+        hid = self._mm(h, pre + ".mlp.fc1", blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias, gelu=True, out_name=f"hid{D}")
+        self._mm(hid, pre + ".mlp.fc2", blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias, res=t_out, out=t_out)
         return t_out
 
     # ---- g_a + quant_conv -----------------------------------------------------------------
@@ -371,26 +441,29 @@ class VAEformer(nn.Module):
         N = self.Hp * self.Wp
         kh, kw = cfg['patch_size']
         sh, sw = cfg['patch_stride']
-        wpe = self._w_patch_embed()
-        cols = self._buf("cols", (N, max(wpe.shape[1], _rup(cfg['out_chans'] * kh * kw, 32))), zero=True)
-        colv = cols[:, : wpe.shape[1]]
-        check = ops.lib().cra5_im2col_f32  # strided destination: call the ABI directly
-        ops._dev(x, mean, std)
-        ops.check(check(ops._p(x.contiguous()), ops._p(mean), ops._p(std), ops._p(cols), cfg['in_chans'],
-                        cfg['img_size'][0], cfg['img_size'][1], kh, kw, sh, sw, self.Hp, self.Wp, cols.stride(0),
-                        ops._stream()), "cra5_im2col_f32")
+        K = cfg['in_chans'] * kh * kw
+        x = x.contiguous()
+        if self.gemm_mode == "split":
+            cols = self._sbuf("pe_cols", N, K, zero=True)   # K padding written once, never touched
+            ops.im2col(x, kh, kw, sh, sw, mean=mean, std=std, out_split=cols)
+        else:
+            cols = self._buf("pe_cols", (N, _rup(K, 32)), zero=True)
+            ops.im2col(x, kh, kw, sh, sw, ldk=cols.shape[1], mean=mean, std=std, out=cols)
         t = self._buf(f"t{D}", (N, D))
-        ops.gemm_nt(colv, wpe, bias=self.g_a.patch_embed.proj.bias, res=self.g_a.pos_embed[0], out=t)
+        self._mm(cols, "g_a.patch_embed.proj", self.g_a.patch_embed.proj.weight, bias=self.g_a.patch_embed.proj.bias,
+                 res=self.g_a.pos_embed[0], out=t)
         blocks = self.g_a.blocks
         grid = (self.Hp, self.Wp)
-        for blk in blocks[:-2]:
-            self._block(blk, t, t, grid)
+        nb = len(blocks)
+        for i in range(nb - 2):
+            self._block(blocks[i], f"g_a.blocks.{i}", t, t, grid)
         mom = self._buf("mom", (N, 2 * D))
-        self._block(blocks[-2], t, mom[:, :D], grid)   # mean
-        self._block(blocks[-1], t, mom[:, D:], grid)   # logvar (vit_nlc.py:468-470)
-        wq = self.quant_conv.weight.view(2 * L, 2 * D)[:L]  # only the `mean` half is ever used
-        ytok = self._buf("ytok", (N, L))
-        ops.gemm_nt(mom, wq, bias=self.quant_conv.bias[:L], out=ytok)
+        self._block(blocks[nb - 2], f"g_a.blocks.{nb - 2}", t, mom[:, :D], grid)   # mean
+        self._block(blocks[nb - 1], f"g_a.blocks.{nb - 1}", t, mom[:, D:], grid)   # logvar (vit_nlc.py:468-470)
+        # only the `mean` half of quant_conv's output is ever used (posterior.mode())
+        wq = self._derive("wq_mean", self.quant_conv.weight, lambda w: w.view(2 * L, -1)[:L].contiguous())
+        ytok = self._mm(self._act(mom, "mom_s"), "quant_conv.mean", wq, bias=self.quant_conv.bias[:L],
+                        out=self._buf("ytok", (N, L)))
         y = torch.empty((L, self.Hp, self.Wp), device=self.device, dtype=torch.float32)
         ops.transpose(ytok, out=y.view(L, N))
         return y
@@ -402,15 +475,20 @@ class VAEformer(nn.Module):
         d = cfg['h_embed_dim']
         zh, zw = cfg['h_patch']
         n = self.Hz * self.Wz
-        cols = ops.im2col(y, zh, zw, zh, zw, out=self._buf("hcols", (n, y.shape[0] * zh * zw)))
-        w = self.h_a.patch_embed.proj.weight
+        K = y.shape[0] * zh * zw
+        if self.gemm_mode == "split":
+            cols = ops.im2col(y, zh, zw, zh, zw, out_split=self._sbuf("hcols", n, K, zero=True))
+        else:
+            cols = ops.im2col(y, zh, zw, zh, zw, out=self._buf("hcols", (n, K)))
         t = self._buf(f"t{d}", (n, d))
-        ops.gemm_nt(cols, w.view(w.shape[0], -1), bias=self.h_a.patch_embed.proj.bias, res=self.h_a.pos_embed[0], out=t)
-        for blk in self.h_a.blocks:
-            self._block(blk, t, t, (self.Hz, self.Wz))
+        self._mm(cols, "h_a.patch_embed.proj", self.h_a.patch_embed.proj.weight, bias=self.h_a.patch_embed.proj.bias,
+                 res=self.h_a.pos_embed[0], out=t)
+        for i, blk in enumerate(self.h_a.blocks):
+            self._block(blk, f"h_a.blocks.{i}", t, t, (self.Hz, self.Wz))
         m = self.h_a.quan_mlp
-        u = ops.gemm_nt(t, m.fc1.weight, bias=m.fc1.bias, gelu=True)
-        ztok = ops.gemm_nt(u, m.fc2.weight, bias=m.fc2.bias)
+        u = self._mm(self._act(t, "ha_t_s"), "h_a.quan_mlp.fc1", m.fc1.weight, bias=m.fc1.bias, gelu=True,
+                     out_name="ha_u")
+        ztok = self._mm(u, "h_a.quan_mlp.fc2", m.fc2.weight, bias=m.fc2.bias)
         return ops.transpose(ztok)  # [Cz, n]
 
     def _h_s_frame(self, z_hat):
@@ -423,13 +501,14 @@ class VAEformer(nn.Module):
         n = self.Hz * self.Wz
         ztok = ops.transpose(z_hat)  # [n, Cz]
         m = self.h_s.post_quan_mlp
-        u = ops.gemm_nt(ztok, m.fc1.weight, bias=m.fc1.bias, gelu=True)
+        u = self._mm(self._act(ztok, "hs_z_s"), "h_s.post_quan_mlp.fc1", m.fc1.weight, bias=m.fc1.bias, gelu=True,
+                     out_name="hs_u")
         t = self._buf(f"t{d}", (n, d))
-        ops.gemm_nt(u, m.fc2.weight, bias=m.fc2.bias, out=t)
-        for blk in self.h_s.blocks:
-            self._block(blk, t, t, (self.Hz, self.Wz))
-        h = ops.layernorm(t, self.h_s.norm.weight, self.h_s.norm.bias, 1e-6)
-        lin = ops.gemm_nt(h, self.h_s.final.weight)
+        self._mm(u, "h_s.post_quan_mlp.fc2", m.fc2.weight, bias=m.fc2.bias, out=t)
+        for i, blk in enumerate(self.h_s.blocks):
+            self._block(blk, f"h_s.blocks.{i}", t, t, (self.Hz, self.Wz))
+        h = self._ln(t, self.h_s.norm, f"h{d}")
+        lin = self._mm(h, "h_s.final", self.h_s.final.weight)
         params = ops.pixel_shuffle(lin, self.Hz, self.Wz, zh, zw)  # [2L, Hp, Wp]
         L = params.shape[0] // 2
         return params[:L], params[L:]
@@ -445,21 +524,16 @@ class VAEformer(nn.Module):
         ytok = self._buf("ytok", (N, L))
         ops.transpose(y_hat.reshape(L, N), out=ytok)
         t = self._buf(f"t{D}", (N, D))
-        ops.gemm_nt(ytok, self.post_quant_conv.weight.view(D, L), bias=self.post_quant_conv.bias, out=t)
-        for blk in self.g_s.blocks:
-            self._block(blk, t, t, (self.Hp, self.Wp))
-        h = self._buf(f"h{D}", (N, D))
-        ops.layernorm(t, self.g_s.norm.weight, self.g_s.norm.bias, 1e-6, out=h)
-        wue = self._w_unembed()
-        ncol = wue.shape[0]
-        wpe_cols = _rup(cfg['in_chans'] * kh * kw, 32)
-        cols = self._buf("cols", (N, max(wpe_cols, _rup(ncol, 32))), zero=True)
-        ops.gemm_nt(h, wue, out=cols[:, :ncol])
+        self._mm(self._act(ytok, "ytok_s"), "post_quant_conv", self.post_quant_conv.weight,
+                 bias=self.post_quant_conv.bias, out=t)
+        for j, blk in enumerate(self.g_s.blocks):
+            self._block(blk, f"g_s.blocks.{j}", t, t, (self.Hp, self.Wp))
+        h = self._ln(t, self.g_s.norm, f"h{D}")
+        ncol = cfg['out_chans'] * kh * kw
+        cols = self._buf("ue_cols", (N, ncol))
+        self._mm(h, "g_s.final", self.g_s.final.weight, out=cols)
         x_hat = torch.empty((cfg['out_chans'],) + tuple(cfg['img_size']), device=self.device, dtype=torch.float32)
-        ops.col2im(cols[:, :ncol], cfg['out_chans'], kh, kw, sh, sw, self.Hp, self.Wp, mean=mean, std=std, out=x_hat)
-        # the patch-embed path relies on the pad columns of `cols` being zero
-        if cols.shape[1] > ncol and wpe_cols > cfg['in_chans'] * kh * kw:
-            cols[:, cfg['in_chans'] * kh * kw: wpe_cols].zero_()
+        ops.col2im(cols, cfg['out_chans'], kh, kw, sh, sw, self.Hp, self.Wp, mean=mean, std=std, out=x_hat)
         return x_hat
 
     # ---- latent side: everything between y and the entropy coder ---------------------------
@@ -480,19 +554,49 @@ class VAEformer(nn.Module):
         return dict(z=z, z_sym=eb["sym"], z_hat=eb["z_hat"], z_lik=eb.get("lik"), scales=scales, means=means,
                     idx=gc.get("idx"), y_sym=gc["sym"], y_hat=gc["y_hat"], y_lik=gc.get("lik"))
 
+    # ---- GPU phases -------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def _gpu_phase(self):
+        """One frame's GPU phase (a run of kernel launches ended by a stream sync, which the
+        device->host hand-off to the entropy coder needs anyway).  When several frames are in
+        flight (cra5_amd/pipeline.py) phases of different frames take turns on the GPU at this
+        granularity while the other frames sit in their host rANS phase: every kernel runs
+        alone on the chip (clean per-kernel timing, no L2 thrash between frames)."""
+        with self._gpu_lock:
+            yield
+            torch.cuda.current_stream().synchronize()
+
+    def _pinned(self, name, shape, dtype):
+        """Per-thread pinned host staging buffer."""
+        ws = getattr(self._tls, "pin", None)
+        if ws is None:
+            ws = self._tls.pin = {}
+        key = (tuple(shape), dtype)
+        b = ws.get(name)
+        if b is None or b[0] != key:
+            b = (key, torch.empty(shape, dtype=dtype, pin_memory=True))
+            ws[name] = b
+        return b[1]
+
+    def _to_host(self, name, t):
+        h = self._pinned(name, t.shape, t.dtype)
+        h.copy_(t, non_blocking=True)
+        return h
+
     # ---- public surface (names / return shapes of the reference) ---------------------------
     @torch.no_grad()
     def encode_latent(self, x, type='quantized'):
         """vaeformer.py:272-292 -> (y, y_hat, y_likelihoods)."""
         self._require_gpu()
         ys, yh, yl = [], [], []
-        for b in range(x.shape[0]):
-            y = self._encode_y_frame(x[b])
-            ys.append(y)
-            if type == "quantized":
-                s = self._latent_side_frame(y, want_lik=True)
-                yh.append(s["y_hat"].reshape(y.shape))
-                yl.append(s["y_lik"].reshape(y.shape))
+        with self._gpu_phase():
+            for b in range(x.shape[0]):
+                y = self._encode_y_frame(x[b])
+                ys.append(y)
+                if type == "quantized":
+                    s = self._latent_side_frame(y, want_lik=True)
+                    yh.append(s["y_hat"].reshape(y.shape))
+                    yl.append(s["y_lik"].reshape(y.shape))
         y = torch.stack(ys)
         if type == "quantized":
             return y, torch.stack(yh), torch.stack(yl)
@@ -502,32 +606,40 @@ class VAEformer(nn.Module):
     def decode_latent(self, y, type='quantized'):
         """vaeformer.py:294-300."""
         self._require_gpu()
-        return torch.stack([self._decode_frame(y[b]) for b in range(y.shape[0])])
+        with self._gpu_phase():
+            return torch.stack([self._decode_frame(y[b]) for b in range(y.shape[0])])
 
     @torch.no_grad()
     def forward(self, x):
         """vaeformer.py:302-333."""
         self._require_gpu()
         xh, yl, zl, ys = [], [], [], []
-        for b in range(x.shape[0]):
-            y = self._encode_y_frame(x[b])
-            s = self._latent_side_frame(y, want_lik=True)
-            xh.append(self._decode_frame(s["y_hat"].reshape(y.shape)))
-            yl.append(s["y_lik"].reshape(y.shape))
-            zl.append(s["z_lik"].reshape(-1, self.Hz, self.Wz))
-            ys.append(y)
+        with self._gpu_phase():
+            for b in range(x.shape[0]):
+                y = self._encode_y_frame(x[b])
+                s = self._latent_side_frame(y, want_lik=True)
+                xh.append(self._decode_frame(s["y_hat"].reshape(y.shape)))
+                yl.append(s["y_lik"].reshape(y.shape))
+                zl.append(s["z_lik"].reshape(-1, self.Hz, self.Wz))
+                ys.append(y)
         return {"x_hat": torch.stack(xh), "likelihoods": {"y": torch.stack(yl), "z": torch.stack(zl)},
                 "posterior": _Posterior(torch.stack(ys))}
 
-    def _strings_from_side(self, s):
+    def _compress_frame(self, x=None, y=None, mean=None, std=None):
+        """GPU phase (g_a + latent side, symbols staged to pinned host memory) followed by the
+        host phase (two rANS streams).  Either x [C,H,W] or y [L,Hp,Wp]."""
         self.entropy_bottleneck._check()
         self.gaussian_conditional._check()
-        z_sym = s["z_sym"].cpu().numpy()
-        y_sym = s["y_sym"].cpu().numpy()
-        idx = s["idx"].cpu().numpy()
+        with self._gpu_phase():
+            if y is None:
+                y = self._encode_y_frame(x, mean=mean, std=std)
+            s = self._latent_side_frame(y.contiguous())
+            z_sym = self._to_host("z_sym", s["z_sym"])
+            y_sym = self._to_host("y_sym", s["y_sym"])
+            idx = self._to_host("idx", s["idx"])
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
-        z_str = self.entropy_bottleneck.encode_symbols(z_sym.reshape(-1), z_idx)
-        y_str = self.gaussian_conditional.encode_symbols(y_sym.reshape(-1), idx.reshape(-1))
+        z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
+        y_str = self.gaussian_conditional.encode_symbols(y_sym.numpy().reshape(-1), idx.numpy().reshape(-1))
         return y_str, z_str
 
     @torch.no_grad()
@@ -536,7 +648,7 @@ class VAEformer(nn.Module):
         self._require_gpu()
         ystr, zstr = [], []
         for b in range(y.shape[0]):
-            a, c = self._strings_from_side(self._latent_side_frame(y[b].contiguous()))
+            a, c = self._compress_frame(y=y[b])
             ystr.append(a)
             zstr.append(c)
         return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
@@ -547,28 +659,37 @@ class VAEformer(nn.Module):
         self._require_gpu()
         ystr, zstr = [], []
         for b in range(x.shape[0]):
-            y = self._encode_y_frame(x[b])
-            a, c = self._strings_from_side(self._latent_side_frame(y))
+            a, c = self._compress_frame(x=x[b])
             ystr.append(a)
             zstr.append(c)
         return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
 
-    def _decompress_latent_frame(self, y_string, z_string, shape):
+    def _decompress_frame(self, y_string, z_string, shape, reconstruct, mean=None, std=None):
+        """host: decode z | GPU: h_s, indexes | host: decode y | GPU: de-quantise (+ g_s)."""
         eb, gc = self.entropy_bottleneck, self.gaussian_conditional
         Cz = eb.channels
         zh, zw = int(shape[0]), int(shape[1])
         z_idx = eb._build_indexes((1, Cz, zh, zw))
-        z_sym = torch.from_numpy(eb.decode_symbols(z_string, z_idx)).to(self.device).view(Cz, zh * zw)
-        med, _ = eb.device_params()
-        z_hat = ops.entropy_bottleneck(med, None, sym_in=z_sym, want=("z_hat",))["z_hat"]
-        scales, means = self._h_s_frame(z_hat)
-        scales, means = scales.contiguous(), means.contiguous()
-        idx = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=torch.zeros_like(means, dtype=torch.int32),
-                                       want=("idx",), scale_bound=float(gc.lower_bound_scale.bound))["idx"]
-        y_sym = torch.from_numpy(gc.decode_symbols(y_string, idx.cpu().numpy().reshape(-1))).to(self.device)
-        y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym.view(means.shape),
-                                         want=("y_hat",))["y_hat"]
-        return y_hat
+        z_host = self._pinned("z_in", (Cz, zh * zw), torch.int32)
+        z_host.copy_(torch.from_numpy(eb.decode_symbols(z_string, z_idx)).view(Cz, zh * zw))
+        with self._gpu_phase():
+            z_sym = z_host.to(self.device, non_blocking=True)
+            med, _ = eb.device_params()
+            z_hat = ops.entropy_bottleneck(med, None, sym_in=z_sym, want=("z_hat",))["z_hat"]
+            scales, means = self._h_s_frame(z_hat)
+            scales, means = scales.contiguous(), means.contiguous()
+            idx = ops.gaussian_conditional(scales, means, gc.scale_table,
+                                           sym_in=torch.zeros_like(means, dtype=torch.int32), want=("idx",),
+                                           scale_bound=float(gc.lower_bound_scale.bound))["idx"]
+            idx_h = self._to_host("idx", idx)
+        y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
+        y_host.copy_(torch.from_numpy(gc.decode_symbols(y_string, idx_h.numpy().reshape(-1))).view(means.shape))
+        with self._gpu_phase():
+            y_sym = y_host.to(self.device, non_blocking=True)
+            y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym, want=("y_hat",))["y_hat"]
+            if not reconstruct:
+                return y_hat
+            return self._decode_frame(y_hat, mean=mean, std=std)
 
     @torch.no_grad()
     def decompress(self, strings, shape, return_format='reconstructed'):
@@ -577,11 +698,12 @@ class VAEformer(nn.Module):
         assert isinstance(strings, list) and len(strings) == 2
         self.entropy_bottleneck._check()
         self.gaussian_conditional._check()
-        y_hat = torch.stack([self._decompress_latent_frame(strings[0][b], strings[1][b], shape)
-                             for b in range(len(strings[0]))])
-        if return_format == 'latent':
-            return y_hat
-        return {"x_hat": self.decode_latent(y_hat)}
+        rec = return_format != 'latent'
+        out = torch.stack([self._decompress_frame(strings[0][b], strings[1][b], shape, rec)
+                           for b in range(len(strings[0]))])
+        if not rec:
+            return out
+        return {"x_hat": out}
 
     @torch.no_grad()
     def prediction(self, inputs):

@@ -92,10 +92,30 @@ int cra5_gemm_nt_f32(const float *A, int lda, const float *W, int ldw, float *C,
                      const float *bias, const float *res, int ldr, int M, int N, int K,
                      int flags, void *stream);
 
+/* Same contraction, fp32-accurate, on the f16 matrix cores (3 x v_mfma_f32_32x32x16_f16 per
+ * product, fp32 accumulate) with both operands in the "split-f16" layout: every fp32 value
+ * x is stored as hi = f16(x), lo = f16(x - hi); a row is a sequence of 128-byte chunks of
+ * [32 hi halves | 32 lo halves], Kp = K rounded up to a multiple of 32 with zero padding
+ * (so a row has 2*Kp halves = the bytes of Kp floats).
+ *   C = epi(wscale_inv * A . W^T); `wscale_inv` undoes the power-of-two scale applied to W
+ *   when it was split.  Outputs: C (fp32, may be NULL) and/or C_split (split-f16 with row
+ *   length ldc_split_kp, may be NULL) - e.g. fc1+GELU writes the split matrix fc2 reads. */
+int cra5_gemm_nt_split(const uint16_t *A, const uint16_t *W, float *C, int ldc, uint16_t *C_split,
+                       int ldc_split_kp, const float *bias, const float *res, int ldr, int M,
+                       int N, int Kp, float wscale_inv, int flags, void *stream);
+
+/* fp32 [rows][K] (row stride ldx) * scale -> split-f16 [rows][2*Kp]. Used once per weight
+ * tensor at load time and for the few activations no fused producer emits. */
+int cra5_split_f16(const float *x, int ldx, uint16_t *out, int rows, int K, int Kp, float scale,
+                   void *stream);
+
 /* LayerNorm over the last dim (eps inside the sqrt), one row per wavefront
- * (partial(nn.LayerNorm, eps=1e-6): vit_nlc.py:266,278,381,626). D % 4 == 0, D <= 2048. */
+ * (partial(nn.LayerNorm, eps=1e-6): vit_nlc.py:266,278,381,626). D % 4 == 0, D <= 2048.
+ * Outputs: y (fp32, may be NULL) and/or y_split (split-f16 rows of 2*split_kp halves, pad
+ * columns zeroed, may be NULL). */
 int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float *beta, float *y,
-                       int ldy, int rows, int D, float eps, void *stream);
+                       int ldy, uint16_t *y_split, int split_kp, int rows, int D, float eps,
+                       void *stream);
 
 /* ============================ device: attention =============================== */
 
@@ -105,20 +125,22 @@ int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float 
  * carries q = k = v = pad_row (the qkv bias) and attention is UNMASKED over the 576
  * tokens of a window (vit_nlc.py:219-258); wh = H, ww = W gives the global attention
  * of vit_nlc.py:94-112.  out: [H*W][C] (pre-projection), padded queries dropped.
- * hd must be 64 or 72. */
-int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out, int C,
-                              int heads, int H, int W, int wh, int ww, float scale,
-                              void *stream);
+ * hd must be 64 or 72.  out (fp32) and/or out_split (split-f16, rows of 2*split_kp halves;
+ * pad columns are NOT written: zero the buffer once) may be NULL. */
+int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out,
+                              uint16_t *out_split, int split_kp, int C, int heads, int H, int W,
+                              int wh, int ww, float scale, void *stream);
 
 /* ============================ device: layout / conv edges ===================== */
 
 /* Patch gather for a strided Conv2d as GEMM (vit_nlc.py:302-308), fused with the API's
  * normalisation (x - mean[c]) / std[c] (cra5_api.py:264-266) when mean != NULL.
  * x: [C][H][W]; cols: [Hp*Wp][ldk], column (c*kh + i)*kw + j; columns >= C*kh*kw are
- * left untouched (keep them zero). */
-int cra5_im2col_f32(const float *x, const float *mean, const float *std, float *cols, int C,
-                    int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk,
-                    void *stream);
+ * left untouched (keep them zero).  cols (fp32) and/or cols_split (split-f16, Kp = ldk,
+ * ldk % 32 == 0) may be NULL. */
+int cra5_im2col_f32(const float *x, const float *mean, const float *std, float *cols,
+                    uint16_t *cols_split, int C, int H, int W, int kh, int kw, int sh, int sw,
+                    int Hp, int Wp, int ldk, void *stream);
 
 /* Overlap-add scatter of a ConvTranspose2d computed as GEMM (vit_nlc.py:628-630,
  * 666-669), fused with de-normalisation x*std[c] + mean[c] (cra5_api.py:268-271) when

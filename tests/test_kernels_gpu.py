@@ -45,6 +45,61 @@ def test_gemm_nt(dev, M, N, K, epi):
     assert relerr(out, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (10368, 1024, 1024), (2048, 4096, 1024), (1000, 360, 360),
+                                   (333, 77, 52), (10368, 1024, 4096), (2048, 1024, 29480), (648, 8192, 360)])
+def test_gemm_split_f16_is_fp32_accurate(dev, M, N, K):
+    """The 3xf16-split MFMA GEMM against float64, side by side with the exact-f32 MFMA kernel:
+    it must be at least as accurate (shorter fp32 accumulation chain), never worse than 1.5x."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 1.7
+    a[::7] *= 8.0                                  # rows with larger dynamic range
+    a[1::13] *= 1e-3                               # and tiny rows (absolute-error regime of lo)
+    w = torch.randn(N, K, generator=g) * 0.02
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double()) + r.double()
+    ad, wd, bd, rd = a.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    f32 = ops.gemm_nt(ad, wd, bias=bd, res=rd, gelu=True) if K % 4 == 0 else None
+    sa = ops.split_f16(ad)
+    sw = ops.split_f16(wd, "auto")
+    assert float((sa.to_float() - ad).abs().max()) <= 2 ** -21 * float(ad.abs().max())   # 22-bit operands
+    out_s = ops.SplitMat.empty(M, N, dev, zero=True)
+    sp = ops.gemm_nt_split(sa, sw, bias=bd, res=rd, gelu=True, out_split=out_s)
+    e_sp = rmse(sp, ref)
+    e_32 = rmse(f32, ref) if f32 is not None else None
+    print(f"gemm {M}x{N}x{K}: split-f16 rmse {e_sp:.2e}" + (f", exact-f32 MFMA rmse {e_32:.2e}" if e_32 else ""))
+    assert relerr(sp, ref) < 2e-6
+    if e_32 is not None:
+        assert e_sp <= 1.5 * e_32 + 1e-9
+    # the split-f16 output written by the epilogue reconstructs the fp32 output to 22 bits
+    assert float((out_s.to_float() - sp).abs().max()) <= 2 ** -21 * float(sp.abs().max()) + 2 ** -24
+
+
+def test_split_producers(dev):
+    """LayerNorm / attention / im2col emit the same values in split-f16 as in fp32."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(648, 360, generator=g).to(dev)
+    ga, be = torch.randn(360, generator=g).to(dev), torch.randn(360, generator=g).to(dev)
+    y = ops.layernorm(x, ga, be)
+    sm = ops.SplitMat.empty(648, 360, dev)
+    ops.layernorm(x, ga, be, out_split=sm, want_f32=False)
+    assert sm.Kp == 384
+    assert float((sm.to_float() - y).abs().max()) <= 2 ** -21 * float(y.abs().max()) + 2 ** -24
+    full = sm.data.view(torch.float16).view(648, 12, 2, 32)
+    assert float(full[:, 11, :, 8:].abs().max()) == 0.0      # K padding zeroed
+    qkv = torch.randn(648, 3 * 144, generator=g).to(dev)
+    pad = torch.zeros(3 * 144, device=dev)
+    o = ops.window_attention(qkv, pad, 2, 18, 36, 18, 36)
+    so = ops.SplitMat.empty(648, 144, dev, zero=True)
+    ops.window_attention(qkv, pad, 2, 18, 36, 18, 36, out_split=so, want_f32=False)
+    assert float((so.to_float() - o).abs().max()) <= 2 ** -21 * float(o.abs().max()) + 2 ** -24
+    img = torch.randn(3, 721, 1440, generator=g).to(dev)
+    c = ops.im2col(img, 11, 10, 10, 10)
+    sc = ops.SplitMat.empty(72 * 144, 330, dev, zero=True)
+    ops.im2col(img, 11, 10, 10, 10, out_split=sc)
+    assert float((sc.to_float() - c).abs().max()) <= 2 ** -21 * float(c.abs().max()) + 2 ** -24
+
+
 def test_gemm_asymmetric_layout(dev):
     """A = I with an asymmetric W catches row/col swaps of the MFMA C layout."""
     n = 128

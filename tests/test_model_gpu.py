@@ -257,7 +257,8 @@ def test_full268_vs_reference_golden(big, dev, golden_dir):
           f"means {e_m:.3e}, scales {e_s:.3e}, idx flips {idx_mis}, sym flips {sym_mis}, "
           f"sym hist L1 {int(np.abs(hist - g['sym_hist']).sum())}, idx hist L1 {int(np.abs(idx_hist - g['idx_hist']).sum())}")
     assert e_y <= 1e-5
-    assert e_z <= 2e-5            # z = h_a(y): 4 more blocks on top of y's 1e-5
+    z_rms = float(np.sqrt(g["z_stats"][1] / s["z"].numel()))
+    assert e_z <= 1e-5 * max(1.0, z_rms)   # z is O(7) with the synthetic gains: relative 1e-5
     assert z_hist_l1 <= 8         # at most a handful of .5-boundary flips in 165 888 symbols
     if z_hist_l1 == 0 and z_flips == 0:
         assert e_m <= 1e-5 and e_s <= 1e-5
