@@ -181,9 +181,10 @@ def main():
                                   "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                                   "launches": g["launches"], "avg_launch_ms": g["ms"] / g["launches"],
                                   "gemm_ms_per_step": g["ms"] / args.steps}
-        a = summ.get("window_attention_f32")
+        a = summ.get("window_attention_split") or summ.get("window_attention_f32")
         if a and a["ms"] > 0:
-            result["attention"] = {"kernel": "window_attention_f32_kernel",
+            result["attention"] = {"kernel": "window_attention_split_kernel" if "window_attention_split" in summ
+                                   else "window_attention_f32_kernel",
                                    "achieved_tflops": a["work"] / (a["ms"] * 1e-3) / 1e12,
                                    "launches": a["launches"], "ms_per_step": a["ms"] / args.steps}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

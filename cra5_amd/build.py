@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcra5_amd.so")
-SOURCES = ["host_entropy.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "attention_f32.hip", "elementwise.hip"]
+SOURCES = ["host_entropy.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "attention_f32.hip", "attention_split_f16.hip", "elementwise.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

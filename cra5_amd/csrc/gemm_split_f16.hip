@@ -19,15 +19,18 @@
 // full-line global loads, and the producers (LayerNorm, GELU epilogue, attention, patch
 // gather) write their output directly in this format - no conversion pass.
 //
-// Kernel structure (per 128x128 tile, 4 waves = one per SIMD, each a 2x2 grid of 32x32
-// accumulators): register-prefetch of the next 4 plane tiles (A hi/lo, W hi/lo) while the
-// current ones are consumed from LDS; LDS rows padded 64 -> 80 bytes so that every
-// ds_read_b128 lane group touches 16 distinct 16-byte slots; 24 MFMAs per wave per step,
-// issued plane-major (4 independent accumulators between dependent MFMAs); XCD-aware
-// tile order; fused bias / exact-erf GELU / residual epilogue with fp32 and/or split-f16
-// output.  Long reductions (K > 8192: the patch-embed conv, K = 29 480) additionally flush
-// the MFMA accumulators into a second fp32 accumulator set every 512 k (two-level sum).
+// Kernel structure: tiles of 256x256 / 192x256 (8 waves = 2 per SIMD, 4x2 / 3x2 32x32
+// accumulators per wave) or 128x128 / 64x64 (4 waves) chosen per shape; two LDS stages of
+// the 4 plane tiles (A hi/lo, W hi/lo), one barrier per BK = 32 step: tile k+1 goes from
+// registers to the idle stage and tile k+2 is fetched from L2/HBM while tile k is consumed;
+// 64-byte LDS rows with an XOR swizzle of the 16-byte piece index (conflict-free
+// ds_read_b128 without padding, so 256x256 double-buffered fits in 128 KB); MFMAs issued
+// plane-major (TM*TN independent accumulators between dependent MFMAs); XCD-aware tile
+// order; fused bias / exact-erf GELU / residual epilogue with fp32 and/or split-f16
+// output.  Long reductions (K > 8192: the patch-embed conv, K = 29 480) are chained through
+// the fp32 output in chunks of <= 8192 (two-level sum).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/cra5_amd.h"
 #include "split.h"
@@ -38,7 +41,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int BK = 32;         // elements per k-step
-constexpr int ROW_H = 40;      // LDS row stride in halves (64 B data + 16 B pad)
+constexpr int ROW_H = 32;      // LDS row = 64 B = 4 x 16-byte pieces (XOR-swizzled, no padding)
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -63,11 +66,12 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
   constexpr int A_P = BM / ROWS_PER_PASS;
   constexpr int B_P = BN / ROWS_PER_PASS;
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/threads mismatch");
+  constexpr int STAGE = (2 * BM + 2 * BN) * ROW_H;  // halves per pipeline stage
 
-  // [A hi][A lo][W hi][W lo], each rows x ROW_H halves
-  __shared__ __attribute__((aligned(16))) unsigned short lds[(2 * BM + 2 * BN) * ROW_H];
-  unsigned short *As = lds;                  // plane p at As + p * BM * ROW_H
-  unsigned short *Bs = lds + 2 * BM * ROW_H;
+  // two stages of [A hi][A lo][W hi][W lo]; rows are 64 B (4 x 16-byte pieces), piece p of row r
+  // lives at physical piece p ^ ((r >> 2) & 3): every ds_read_b128 lane group (16 rows, one
+  // logical piece) then touches 16 distinct 16-byte slots - conflict-free without padding.
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * STAGE];
 
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = pid / tiles_n, tn = pid % tiles_n;
@@ -78,9 +82,13 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int c8 = tid & 7;       // 16-byte piece of the 128-byte chunk: 0-3 hi, 4-7 lo
-  const int r0 = tid >> 3;
+  // staging map: thread -> (row, plane, logical piece).  The lo plane of row r^1 rides with
+  // the hi plane of row r so that the 8 lanes of a ds_write_b128 group hit both bank halves.
+  const int c8 = tid & 7;
   const int plane = c8 >> 2, pc = c8 & 3;
+  const int r0 = (tid >> 3) ^ plane;
+  const int wr_off = plane * ROW_H / 2 * 0;  // (planes are separate arrays; kept for clarity)
+  (void)wr_off;
 
   uint4 ra[A_P], rb[B_P];
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
@@ -90,20 +98,28 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
     _Pragma("unroll") for (int p = 0; p < A_P; ++p) {                                          \
       const int r_ = m0 + r0 + p * ROWS_PER_PASS;                                              \
       ra[p] = zero4;                                                                           \
-      if (r_ < M) ra[p] = *reinterpret_cast<const uint4 *>(A + (size_t)r_ * lda + (size_t)(KT)*64 + c8 * 8); \
+      if (r_ < M)                                                                              \
+        ra[p] = *reinterpret_cast<const uint4 *>(A + (size_t)r_ * lda + (size_t)(KT)*64 + plane * 32 + pc * 8); \
     }                                                                                          \
     _Pragma("unroll") for (int p = 0; p < B_P; ++p) {                                          \
       const int r_ = n0 + r0 + p * ROWS_PER_PASS;                                              \
       rb[p] = zero4;                                                                           \
-      if (r_ < N) rb[p] = *reinterpret_cast<const uint4 *>(W + (size_t)r_ * ldw + (size_t)(KT)*64 + c8 * 8); \
+      if (r_ < N)                                                                              \
+        rb[p] = *reinterpret_cast<const uint4 *>(W + (size_t)r_ * ldw + (size_t)(KT)*64 + plane * 32 + pc * 8); \
     }                                                                                          \
   }
-#define CRA5_SSTORE()                                                                          \
+#define CRA5_SSTORE(BUF)                                                                       \
   {                                                                                            \
-    _Pragma("unroll") for (int p = 0; p < A_P; ++p)                                            \
-        *reinterpret_cast<uint4 *>(As + plane * BM * ROW_H + (r0 + p * ROWS_PER_PASS) * ROW_H + pc * 8) = ra[p]; \
-    _Pragma("unroll") for (int p = 0; p < B_P; ++p)                                            \
-        *reinterpret_cast<uint4 *>(Bs + plane * BN * ROW_H + (r0 + p * ROWS_PER_PASS) * ROW_H + pc * 8) = rb[p]; \
+    unsigned short *as_ = lds + (BUF)*STAGE + plane * BM * ROW_H;                              \
+    unsigned short *bs_ = lds + (BUF)*STAGE + 2 * BM * ROW_H + plane * BN * ROW_H;             \
+    _Pragma("unroll") for (int p = 0; p < A_P; ++p) {                                          \
+      const int r_ = r0 + p * ROWS_PER_PASS;                                                   \
+      *reinterpret_cast<uint4 *>(as_ + r_ * ROW_H + ((pc ^ ((r_ >> 2) & 3)) << 3)) = ra[p];    \
+    }                                                                                          \
+    _Pragma("unroll") for (int p = 0; p < B_P; ++p) {                                          \
+      const int r_ = r0 + p * ROWS_PER_PASS;                                                   \
+      *reinterpret_cast<uint4 *>(bs_ + r_ * ROW_H + ((pc ^ ((r_ >> 2) & 3)) << 3)) = rb[p];    \
+    }                                                                                          \
   }
 
   f32x16 acc[TM][TN];
@@ -118,28 +134,38 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
         if (LONGK) master[i][j][r] = 0.f;
       }
 
-  const unsigned short *a_base = As + (wm * TM * 32 + l31) * ROW_H + h * 8;
-  const unsigned short *b_base = Bs + (wn * TN * 32 + l31) * ROW_H + h * 8;
+  // fragment read offsets (halves) inside a stage: row * 32 + ((2*kk + h) ^ sw) * 8
+  const int sw = (l31 >> 2) & 3;
+  const int a_row = (wm * TM * 32 + l31) * ROW_H;
+  const int b_row = 2 * BM * ROW_H + (wn * TN * 32 + l31) * ROW_H;
+  int poff[2];
+  poff[0] = ((0 + h) ^ sw) << 3;
+  poff[1] = ((2 + h) ^ sw) << 3;
 
   const int nk = Kp / BK;
   CRA5_GLOAD(0);
-  CRA5_SSTORE();
+  CRA5_SSTORE(0);
+  if (nk > 1) CRA5_GLOAD(1);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) CRA5_GLOAD(kt + 1);
+    const int cur = kt & 1;
+    // tile kt+1 (in registers since the previous step) -> the other stage, then prefetch kt+2
+    if (kt + 1 < nk) CRA5_SSTORE(cur ^ 1);
+    if (kt + 2 < nk) CRA5_GLOAD(kt + 2);
+    const unsigned short *st = lds + cur * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       half8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const half8 *>(a_base + i * 32 * ROW_H + kk * 16);
-        al[i] = *reinterpret_cast<const half8 *>(a_base + BM * ROW_H + i * 32 * ROW_H + kk * 16);
+        ah[i] = *reinterpret_cast<const half8 *>(st + a_row + i * 32 * ROW_H + poff[kk]);
+        al[i] = *reinterpret_cast<const half8 *>(st + a_row + BM * ROW_H + i * 32 * ROW_H + poff[kk]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const half8 *>(b_base + j * 32 * ROW_H + kk * 16);
-        bl[j] = *reinterpret_cast<const half8 *>(b_base + BN * ROW_H + j * 32 * ROW_H + kk * 16);
+        bh[j] = *reinterpret_cast<const half8 *>(st + b_row + j * 32 * ROW_H + poff[kk]);
+        bl[j] = *reinterpret_cast<const half8 *>(st + b_row + BN * ROW_H + j * 32 * ROW_H + poff[kk]);
       }
       // small terms first, plane-major: TM*TN independent accumulators between dependent MFMAs
 #pragma unroll
@@ -169,11 +195,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
             acc[i][j][r] = 0.f;
           }
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      CRA5_SSTORE();
-      __syncthreads();
-    }
+    __syncthreads();   // stage cur fully consumed, stage cur^1 fully written
   }
 
   const bool has_bias = flags & CRA5_EPI_BIAS;
@@ -182,22 +204,40 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + l31;
-    if (n >= N) continue;
-    const float bv = has_bias ? bias[n] : 0.f;
+    if (n0 + (wn * TN + j) * 32 >= N) continue;   // wave-uniform (the shuffle below needs all lanes)
+    const float bv = (has_bias && n < N) ? bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mb = m0 + (wm * TM + i) * 32 + 4 * h;
+      float vout[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m < M) {
+        vout[r] = 0.f;
+        if (m < M && n < N) {
           float v = acc[i][j][r];
           if (LONGK) v += master[i][j][r];
           v = v * wscale_inv + bv;
           if (do_gelu) v = gelu_erf(v);
           if (has_res) v += res[(size_t)m * ldr + n];
+          vout[r] = v;
           if (C) C[(size_t)m * ldc + n] = v;
-          if (Cs) cra5_store_split(Cs + (size_t)m * ldcs, n, v);
+        }
+        if (Cs) {
+          // split-f16 store, 4 bytes per lane: lane pairs (2i, 2i+1) hold adjacent columns;
+          // the even lane stores the packed hi pair, the odd lane the packed lo pair ->
+          // one full 128-byte chunk [32 hi | 32 lo] per row per half-wave.
+          const _Float16 hi = (_Float16)vout[r];
+          const _Float16 lo = (_Float16)(vout[r] - (float)hi);
+          const unsigned int mine = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
+                                    ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
+          const unsigned int other = (unsigned int)__shfl_xor((int)mine, 1, 64);
+          const bool odd = lane & 1;
+          // even: (hi_own, hi_next)   odd: (lo_prev, lo_own)
+          const unsigned int word = odd ? ((other >> 16) | (mine & 0xFFFF0000u)) : ((mine & 0xFFFFu) | (other << 16));
+          const int nn = n & ~1;
+          if (m < M && nn + 1 < ((N + 1) & ~1))
+            *reinterpret_cast<unsigned int *>(Cs + (size_t)m * ldcs + (nn >> 5) * 64 + (odd ? 32 : 0) + (nn & 31)) = word;
         }
       }
     }
@@ -229,22 +269,62 @@ int launch(const unsigned short *A, long lda, const unsigned short *W, long ldw,
 
 }  // namespace
 
-extern "C" int cra5_gemm_nt_split(const uint16_t *A, const uint16_t *W, float *C, int ldc, uint16_t *C_split,
-                                  int ldc_split_kp, const float *bias, const float *res, int ldr, int M, int N,
-                                  int Kp, float wscale_inv, int flags, void *stream) {
+static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C, int ldc,
+                         unsigned short *C_split, long ldcs, const float *bias, const float *res, int ldr, int M,
+                         int N, int Kp, float wscale_inv, int flags, hipStream_t st) {
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+#define CRA5_GO(WM, WN, TM, TN, LK) \
+  return launch<WM, WN, TM, TN, LK>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st)
+  static const int forced = [] {
+    const char *e = getenv("CRA5_GEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  const bool longk = Kp > 8192;
+  if (longk) CRA5_GO(2, 2, 2, 2, true);
+  int tile = forced;
+  if (!tile) {
+    // measured on MI355X (tools/gemm_bench.py, M = 10368): N = 1024 (proj, fc2, patch-embed):
+    // 192x256 tiles = 216 blocks, one round on 256 CUs; N >= 3072: 256x256 tiles.
+    if (tiles128 < 256) tile = 64;
+    else if (M >= 1024 && N >= 2048) tile = 256;
+    else if (M >= 1024 && N >= 512) tile = 192;
+    else tile = 128;
+  }
+  if (tile == 64) CRA5_GO(2, 2, 1, 1, false);
+  if (tile == 192) CRA5_GO(2, 4, 3, 2, false);   // 192 x 256, 8 waves (2 x 4), 3 x 2 sub-tiles per wave
+  if (tile == 256) CRA5_GO(2, 4, 4, 2, false);   // 256 x 256, 8 waves (2 x 4), 4 x 2 sub-tiles per wave
+  CRA5_GO(2, 2, 2, 2, false);
+#undef CRA5_GO
+}
+
+extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw_kp, float *C, int ldc,
+                                  uint16_t *C_split, int ldc_split_kp, const float *bias, const float *res, int ldr,
+                                  int M, int N, int Kp, float wscale_inv, int flags, void *stream) {
   if (!A || !W || (!C && !C_split) || M <= 0 || N <= 0 || Kp <= 0 || (Kp % BK)) return CRA5_ERR_ARG;
+  if (lda_kp < Kp || ldw_kp < Kp || (lda_kp % 32) || (ldw_kp % 32)) return CRA5_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return CRA5_ERR_ARG;
   if ((flags & CRA5_EPI_BIAS) && !bias) return CRA5_ERR_ARG;
   if ((flags & CRA5_EPI_RES) && !res) return CRA5_ERR_ARG;
   if (C_split && (ldc_split_kp % 32 || ldc_split_kp < N)) return CRA5_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const long ld = 2L * Kp, ldcs = 2L * ldc_split_kp;
-  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (Kp > 8192)
-    return launch<2, 2, 2, 2, true>(A, ld, W, ld, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
-  if (tiles128 < 256)
-    return launch<2, 2, 1, 1, false>(A, ld, W, ld, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
-  return launch<2, 2, 2, 2, false>(A, ld, W, ld, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+  const long lda = 2L * lda_kp, ldw = 2L * ldw_kp, ldcs = 2L * ldc_split_kp;
+  // Long reductions (patch-embed conv, K = 29 480): K is cut into chunks of <= 8192 whose
+  // partial products are chained through the fp32 C matrix (C += A_i . W_i): a two-level
+  // sum (each chunk accumulates in the MFMA accumulators, chunks add in fp32) without a
+  // second accumulator register set, so the big tiles stay spill-free.
+  if (Kp > 8192 && C && !C_split && !(flags & CRA5_EPI_GELU)) {
+    const int nchunk = (Kp + 8191) / 8192;
+    const int per = ((Kp / 32 + nchunk - 1) / nchunk) * 32;
+    for (int k0 = 0, i = 0; k0 < Kp; k0 += per, ++i) {
+      const int kc = (Kp - k0 < per) ? Kp - k0 : per;
+      const int f = (i == 0) ? flags : CRA5_EPI_RES;
+      const int rc = gemm_dispatch(A + 2L * k0, lda, W + 2L * k0, ldw, C, ldc, nullptr, 0, (i == 0) ? bias : nullptr,
+                                   (i == 0) ? res : C, (i == 0) ? ldr : ldc, M, N, kc, wscale_inv, f, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  return gemm_dispatch(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
 }
 
 extern "C" int cra5_split_f16(const float *x, int ldx, uint16_t *out, int rows, int K, int Kp, float scale,

@@ -163,7 +163,8 @@ def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=Non
         assert out_split.rows == M and out_split.K == N
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
     ev = TIMER.start() if TIMER is not None else None
-    check(lib().cra5_gemm_nt_split(_p(a.data), _p(w.data), _p(out), _row_stride(out) if out is not None else 0,
+    check(lib().cra5_gemm_nt_split(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
+                                   _row_stride(out) if out is not None else 0,
                                    _p(out_split.data) if out_split is not None else None,
                                    out_split.Kp if out_split is not None else 0, _p(bias), _p(res),
                                    _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv), flags,
@@ -211,6 +212,29 @@ def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None, out_split=None
         L = wh * ww
         TIMER.stop("window_attention_f32", ev, 4.0 * N * L * C)
     return out if out is not None else out_split
+
+
+def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None):
+    """qkv_s: SplitMat [H*W, 3C]; pad_s: SplitMat [1, 3C] (the split qkv bias)."""
+    _devs(qkv_s.data, pad_s.data)
+    _dev(out)
+    N, C = qkv_s.rows, qkv_s.K // 3
+    assert N == H * W and qkv_s.Kp == 3 * C and pad_s.Kp == 3 * C
+    if out_split is not None:
+        assert out_split.rows == N and out_split.K == C
+    scale = float((C // heads) ** -0.5)
+    ev = TIMER.start() if TIMER is not None else None
+    check(lib().cra5_window_attention_split(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
+                                            _p(out_split.data) if out_split is not None else None,
+                                            out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
+                                            scale, _stream()), "cra5_window_attention_split")
+    if ev is not None:
+        TIMER.stop("window_attention_split", ev, 4.0 * N * (wh * ww) * C)
+    return out if out is not None else out_split
+
+
+def split_attention_ok(C, heads, wh, ww):
+    return C % heads == 0 and C // heads == 64 and (wh * ww) % 32 == 0
 
 
 def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split=None):

@@ -257,6 +257,7 @@ class VAEformer(nn.Module):
         self.h_s = _Decoder(hd, hh, [None] * (cfg['h_depth'] - n_h),
                             _Linear(hd, 2 * cfg['h_in_chans'] * zh * zw, bias=False), cfg['z_dim'])
         self.gaussian_conditional = GaussianConditional(None)
+        self.attn_mode = os.environ.get("CRA5_ATTN", "split")   # "split" (f16-MFMA, fp32-accurate) | "f32"
         self.gemm_mode = os.environ.get("CRA5_GEMM", "split")
         if self.gemm_mode not in ("split", "f32"):
             raise ValueError("CRA5_GEMM must be 'split' or 'f32'")
@@ -418,9 +419,21 @@ class VAEformer(nn.Module):
         H, W = grid
         split = self.gemm_mode == "split"
         h = self._ln(t_in, blk.norm1, f"h{D}")
+        wh, ww = blk.window if blk.window is not None else (H, W)
+        if split and self.attn_mode == "split" and ops.split_attention_ok(D, blk.heads, wh, ww):
+            # qkv never exists in fp32: GEMM epilogue -> split-f16 -> f16-MFMA attention -> split
+            qkv_s = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out_name=f"qkv{D}")
+            pad_s = self._derive("pad." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)))
+            att = self._sbuf(f"att{D}", N, D, zero=True)
+            ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att)
+            self._mm(att, pre + ".attn.proj", blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
+            h = self._ln(t_out, blk.norm2, f"h{D}")
+            hid = self._mm(h, pre + ".mlp.fc1", blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias, gelu=True,
+                           out_name=f"hid{D}")
+            self._mm(hid, pre + ".mlp.fc2", blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias, res=t_out, out=t_out)
+            return t_out
         qkv = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias,
                        out=self._buf(f"qkv{D}", (N, 3 * D)))
-        wh, ww = blk.window if blk.window is not None else (H, W)
         if split:
             att = self._sbuf(f"att{D}", N, D, zero=True)   # pad columns stay zero
             ops.window_attention(qkv, blk.attn.qkv.bias, blk.heads, H, W, wh, ww, out_split=att, want_f32=False)

@@ -99,10 +99,12 @@ int cra5_gemm_nt_f32(const float *A, int lda, const float *W, int ldw, float *C,
  * (so a row has 2*Kp halves = the bytes of Kp floats).
  *   C = epi(wscale_inv * A . W^T); `wscale_inv` undoes the power-of-two scale applied to W
  *   when it was split.  Outputs: C (fp32, may be NULL) and/or C_split (split-f16 with row
- *   length ldc_split_kp, may be NULL) - e.g. fc1+GELU writes the split matrix fc2 reads. */
-int cra5_gemm_nt_split(const uint16_t *A, const uint16_t *W, float *C, int ldc, uint16_t *C_split,
-                       int ldc_split_kp, const float *bias, const float *res, int ldr, int M,
-                       int N, int Kp, float wscale_inv, int flags, void *stream);
+ *   length ldc_split_kp, may be NULL) - e.g. fc1+GELU writes the split matrix fc2 reads.
+ *   lda_kp / ldw_kp: row length (in K elements, multiples of 32) of the A / W buffers. */
+int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw_kp, float *C,
+                       int ldc, uint16_t *C_split, int ldc_split_kp, const float *bias,
+                       const float *res, int ldr, int M, int N, int Kp, float wscale_inv,
+                       int flags, void *stream);
 
 /* fp32 [rows][K] (row stride ldx) * scale -> split-f16 [rows][2*Kp]. Used once per weight
  * tensor at load time and for the few activations no fused producer emits. */
@@ -130,6 +132,15 @@ int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float 
 int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out,
                               uint16_t *out_split, int split_kp, int C, int heads, int H, int W,
                               int wh, int ww, float scale, void *stream);
+
+/* Same attention, fp32-accurate on the f16 matrix cores (hi/lo operand split, see
+ * cra5_gemm_nt_split), reading the split-f16 qkv matrix [H*W][3C] the qkv projection wrote
+ * (qkv_kp = 3C) and a split pad row, writing fp32 `out` and/or split-f16 `out_split`.
+ * Requires head dim 64 and wh*ww % 32 == 0 (the 576-token windows and the 10 368-token global
+ * attention); other shapes use cra5_window_attention_f32. */
+int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
+                                float *out, uint16_t *out_split, int out_kp, int C, int heads,
+                                int H, int W, int wh, int ww, float scale, void *stream);
 
 /* ============================ device: layout / conv edges ===================== */
 

@@ -158,6 +158,51 @@ def test_window_attention_hd64(dev, ws):
     assert rmse(out, ref[0]) < 4e-6, rmse(out, ref[0])
 
 
+@pytest.mark.parametrize("ws", [(24, 24), (12, 48), (48, 12), None])
+def test_window_attention_split_f16(dev, ws):
+    """f16-split MFMA attention (split qkv in, split out) vs float64; must match the exact-f32
+    kernel's accuracy class."""
+    H, W, C, heads = 72, 144, 128, 2
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, H * W, C, generator=g)
+    shapes = {"attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,), "attn.proj.weight": (C, C),
+              "attn.proj.bias": (C,)}
+    sd = synth.fill_state_dict(shapes, seed=21)
+    sd["attn.qkv.weight"] *= 3.0
+    xd = {k: v.double() for k, v in sd.items()}
+    ref = R.attention_global(x.double(), xd, "attn", heads) if ws is None else \
+        R.attention_window(x.double(), xd, "attn", heads, H, W, ws)
+    wh, ww = ws if ws is not None else (H, W)
+    xs = ops.split_f16(x[0].to(dev))
+    qkv_s = ops.SplitMat.empty(H * W, 3 * C, dev)
+    ops.gemm_nt_split(xs, ops.split_f16(sd["attn.qkv.weight"].to(dev), "auto"), bias=sd["attn.qkv.bias"].to(dev),
+                      out_split=qkv_s, want_f32=False)
+    pad_s = ops.split_f16(sd["attn.qkv.bias"].to(dev).reshape(1, -1))
+    att = ops.SplitMat.empty(H * W, C, dev, zero=True)
+    ops.window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out_split=att)
+    out = ops.gemm_nt_split(att, ops.split_f16(sd["attn.proj.weight"].to(dev), "auto"), bias=sd["attn.proj.bias"].to(dev))
+    e_split = rmse(out, ref[0])
+    e_f32 = rmse(_attn_gpu(x[0], sd, "attn", heads, H, W, ws, dev), ref[0])
+    print(f"attention {ws}: split-f16 rmse {e_split:.2e}, exact-f32 rmse {e_f32:.2e}")
+    assert e_split < 4e-6 and e_split <= 1.5 * e_f32 + 1e-8
+
+
+def test_attention_split_softmax_spike(dev):
+    """Late dominant key: forces the (exactly skipped / taken) online-softmax rescale branch."""
+    H, W, C, heads = 8, 72, 64, 1
+    N = H * W
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(N, 3 * C, generator=g)
+    qkv[:, C:2 * C] *= 0.1
+    qkv[500, C:2 * C] = qkv[17, :C] * 4.0
+    q, k, v = qkv[:, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
+    ref = torch.softmax((q * C ** -0.5) @ k.t(), -1) @ v
+    qs = ops.split_f16(qkv.to(dev))
+    pad = ops.split_f16(torch.zeros(1, 3 * C, device=dev))
+    out = ops.window_attention_split(qs, pad, heads, H, W, H, W, out=torch.empty(N, C, device=dev))
+    assert rmse(out, ref) < 2e-6
+
+
 def test_global_attention_hd72_ragged(dev):
     """648 tokens (not a multiple of the 32-key tile) and head dim 72: hyper-prior shape."""
     H, W, C, heads = 18, 36, 144, 2
