@@ -95,7 +95,12 @@ def main():
     ap.add_argument("--quality", type=int, default=268)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "3")),
+    ap.add_argument("--exclusive", action="store_true",
+                    help="timed region with exclusive GPU phases (one frame's kernels at a time) instead of "
+                         "overlapping HIP streams")
+    ap.add_argument("--roofline-steps", type=int, default=2,
+                    help="frames of the un-overlapped kernel-timing pass run after the timed region")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "6")),
                     help="frames in flight per GPU (host rANS of one frame overlaps GPU work of the others)")
     args = ap.parse_args()
 
@@ -125,6 +130,11 @@ def main():
     net.compress(frames[0])
     pipe.roundtrip([frames[i % 2] for i in range(max(args.warmup, args.inflight))])
     timer = None if args.no_kernel_timer else ops.KernelTimer()
+    # Timed region: frames in flight on separate HIP streams.  By default their GPU phases
+    # OVERLAP on the chip (blocks of one frame's kernels fill the tail / epilogue gaps of
+    # another's: +15-25 % frames/s), which makes a single launch's start->stop duration
+    # depend on what else is running; --exclusive serialises the phases instead.
+    net.gpu_exclusive = bool(args.exclusive)
     torch.cuda.synchronize()
     D.barrier()
     ops.TIMER = timer
@@ -158,8 +168,18 @@ def main():
         "model_tflops": FLOP_PER_FRAME * fps / 1e12,
         "mfma_fraction_end_to_end": FLOP_PER_FRAME * fps / world / (PEAK_FP32_MFMA_TFLOPS * 1e12),
     }
-    if timer is not None:
-        summ = timer.summary()
+    def measured_traffic():
+        """HBM-side bytes per gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE
+        x2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); PMC collection needs its
+        own profiler runs, so bench.py reports the committed measurement, not a live one."""
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            return t["gemm_nt_split"]["avg_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            return None
+
+    def roofline_from(summ, steps):
+        out = {}
         g = summ.get("gemm_nt_split")
         if g and g["ms"] > 0:
             # algorithmic (fp32-equivalent) flops: 2*M*N*K per launch.  The kernel issues 3 f16
@@ -167,26 +187,52 @@ def main():
             # f16 MFMA peak / 3.
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             peak = PEAK_F16_MFMA_TFLOPS / 3.0
-            result["roofline"] = {"kernel": "gemm_nt_split_kernel", "bound": "mfma", "achieved": ach,
-                                  "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                                  "peak_note": "dense f16 MFMA peak 2500 TF / 3 MFMAs per fp32-accurate product",
-                                  "mfma_tflops_issued": 3.0 * ach,
-                                  "launches": g["launches"], "avg_launch_ms": g["ms"] / g["launches"],
-                                  "gemm_ms_per_step": g["ms"] / args.steps}
+            out["roofline"] = {"kernel": "gemm_nt_split_kernel", "bound": "mfma", "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": measured_traffic(),
+                               "traffic_note": "bytes/launch at the L2<->fabric boundary (Infinity-Cache hits "
+                                               "included), profiles/r01_traffic.json; algorithmic minimum "
+                                               "A + W + C = 55-230 MB/launch",
+                               "peak_note": "dense f16 MFMA peak 2500 TF / 3 MFMAs per fp32-accurate product",
+                               "mfma_tflops_issued": 3.0 * ach, "launches": g["launches"],
+                               "avg_launch_ms": g["ms"] / g["launches"], "gemm_ms_per_step": g["ms"] / steps}
         g = summ.get("gemm_nt_f32")
-        if g and g["ms"] > 0 and "roofline" not in result:
+        if g and g["ms"] > 0 and "roofline" not in out:
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "gemm_nt_f32_kernel", "bound": "mfma", "achieved": ach,
-                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                                  "launches": g["launches"], "avg_launch_ms": g["ms"] / g["launches"],
-                                  "gemm_ms_per_step": g["ms"] / args.steps}
+            out["roofline"] = {"kernel": "gemm_nt_f32_kernel", "bound": "mfma", "achieved": ach,
+                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": None, "launches": g["launches"], "avg_launch_ms": g["ms"] / g["launches"],
+                               "gemm_ms_per_step": g["ms"] / steps}
         a = summ.get("window_attention_split") or summ.get("window_attention_f32")
         if a and a["ms"] > 0:
-            result["attention"] = {"kernel": "window_attention_split_kernel" if "window_attention_split" in summ
-                                   else "window_attention_f32_kernel",
-                                   "achieved_tflops": a["work"] / (a["ms"] * 1e-3) / 1e12,
-                                   "launches": a["launches"], "ms_per_step": a["ms"] / args.steps}
+            out["attention"] = {"kernel": "window_attention_split_kernel" if "window_attention_split" in summ
+                                else "window_attention_f32_kernel",
+                                "achieved_tflops": a["work"] / (a["ms"] * 1e-3) / 1e12,
+                                "launches": a["launches"], "ms_per_step": a["ms"] / steps}
+        return out
+
+    if timer is not None:
+        timed = roofline_from(timer.summary(), args.steps)
+        if args.exclusive or args.inflight == 1:
+            result.update(timed)
+            result["roofline"]["measured_over"] = "the timed region (exclusive GPU phases: every launch runs alone)"
+        else:
+            # Kernels of concurrent frames overlapped in the timed region, so start->stop of one
+            # launch also contains other frames' kernels.  Keep those raw numbers, and time the
+            # SAME kernels un-overlapped in a short extra pass (outside the timed region).
+            result["roofline_timed_region"] = timed.get("roofline")
+            result["attention_timed_region"] = timed.get("attention")
+            net.gpu_exclusive = True
+            ops.TIMER = t2 = ops.KernelTimer()
+            pipe.roundtrip([frames[i % 2] for i in range(args.roofline_steps)])
+            torch.cuda.synchronize()
+            ops.TIMER = None
+            result.update(roofline_from(t2.summary(), args.roofline_steps))
+            if "roofline" in result:
+                result["roofline"]["measured_over"] = (
+                    f"a separate un-overlapped pass of {args.roofline_steps} frames run right after the timed "
+                    "region (HIP events on the launch stream, exclusive GPU phases); `roofline_timed_region` "
+                    "holds the same measurement taken inside the timed region, where launches of concurrent "
+                    "frames overlap and per-launch durations are inflated")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(args.quality, os.cpu_count() or 1)

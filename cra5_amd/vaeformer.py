@@ -257,6 +257,9 @@ class VAEformer(nn.Module):
         self.h_s = _Decoder(hd, hh, [None] * (cfg['h_depth'] - n_h),
                             _Linear(hd, 2 * cfg['h_in_chans'] * zh * zw, bias=False), cfg['z_dim'])
         self.gaussian_conditional = GaussianConditional(None)
+        # GPU phases of concurrent frames: exclusive (one frame's kernels at a time) or shared
+        # (streams overlap: other frames' blocks fill the tail / epilogue gaps of a kernel)
+        self.gpu_exclusive = os.environ.get("CRA5_GPU_EXCLUSIVE", "1") != "0"
         self.attn_mode = os.environ.get("CRA5_ATTN", "split")   # "split" (f16-MFMA, fp32-accurate) | "f32"
         self.gemm_mode = os.environ.get("CRA5_GEMM", "split")
         if self.gemm_mode not in ("split", "f32"):
@@ -562,7 +565,7 @@ class VAEformer(nn.Module):
             want = tuple(w for w in want if w != "idx")
         gc = ops.gaussian_conditional(scales.contiguous(), means.contiguous(), st if st.numel() else None,
                                       y=y.contiguous(), want=want,
-                                      scale_bound=float(self.gaussian_conditional.lower_bound_scale.bound),
+                                      scale_bound=self._scale_bound(),
                                       lik_bound=self.gaussian_conditional.likelihood_bound)
         return dict(z=z, z_sym=eb["sym"], z_hat=eb["z_hat"], z_lik=eb.get("lik"), scales=scales, means=means,
                     idx=gc.get("idx"), y_sym=gc["sym"], y_hat=gc["y_hat"], y_lik=gc.get("lik"))
@@ -575,9 +578,24 @@ class VAEformer(nn.Module):
         flight (cra5_amd/pipeline.py) phases of different frames take turns on the GPU at this
         granularity while the other frames sit in their host rANS phase: every kernel runs
         alone on the chip (clean per-kernel timing, no L2 thrash between frames)."""
+        if not self.gpu_exclusive:
+            yield
+            torch.cuda.current_stream().synchronize()
+            return
         with self._gpu_lock:
             yield
             torch.cuda.current_stream().synchronize()
+
+    def _scale_bound(self):
+        """GaussianConditional.lower_bound_scale.bound as a host float, cached: reading a device
+        buffer with float() is a full device sync in the middle of a GPU phase."""
+        b = self.gaussian_conditional.lower_bound_scale.bound
+        key = (b.data_ptr(), b._version)
+        c = self.__dict__.get("_sb_cache")
+        if c is None or c[0] != key:
+            c = (key, float(b.detach().cpu()))
+            self.__dict__["_sb_cache"] = c
+        return c[1]
 
     def _pinned(self, name, shape, dtype):
         """Per-thread pinned host staging buffer."""
@@ -693,7 +711,7 @@ class VAEformer(nn.Module):
             scales, means = scales.contiguous(), means.contiguous()
             idx = ops.gaussian_conditional(scales, means, gc.scale_table,
                                            sym_in=torch.zeros_like(means, dtype=torch.int32), want=("idx",),
-                                           scale_bound=float(gc.lower_bound_scale.bound))["idx"]
+                                           scale_bound=self._scale_bound())["idx"]
             idx_h = self._to_host("idx", idx)
         y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
         y_host.copy_(torch.from_numpy(gc.decode_symbols(y_string, idx_h.numpy().reshape(-1))).view(means.shape))
