@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcra5_amd.so")
+LIB_PATH = os.environ.get("CRA5_LIB") or os.path.join(_HERE, "libcra5_amd.so")  # CRA5_LIB: A/B builds
 
 c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 P = ctypes.POINTER

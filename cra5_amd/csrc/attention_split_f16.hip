@@ -68,7 +68,22 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
   // [K hi][K lo] : 32 x KS ;  [V^T hi][V^T lo] : 64 x VS
   constexpr int KPL = 32 * KS + 32;   // K plane stride (halves): +64 B so hi/lo planes hit different bank halves
   constexpr int VPL = 64 * VS + 8;    // V^T plane stride: +16 B
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * KPL + 2 * VPL];
+#ifdef ATT_UNCOND
+#define ATT_IDX(x) min((x), PIECES - 1)
+#define ATT_IF(c)
+#else
+#define ATT_IDX(x) (x)
+#define ATT_IF(c) if (c)
+#endif
+#ifdef ATT_SB
+#define ATT_SCHED() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ATT_SCHED()
+#endif
+#ifndef ATT_LDS_PAD
+#define ATT_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * KPL + 2 * VPL + ATT_LDS_PAD];
   unsigned short *Ks = lds;
   unsigned short *Vt = lds + 2 * KPL;
 
@@ -116,10 +131,10 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
 #define CRA5_KV_LOAD(J)                                                                   \
   {                                                                                       \
     _Pragma("unroll") for (int p = 0; p < STG; ++p) {                                     \
-      const int idx = tid + p * NT;                                                       \
+      const int idx = ATT_IDX(tid + p * NT);                                             \
       sk[p] = zero4;                                                                      \
       sv[p] = zero4;                                                                      \
-      if (idx < PIECES) {                                                                 \
+      ATT_IF(idx < PIECES) {                                                              \
         /* K: 16 lanes cover one 256-byte row (coalesced).  V: 32 lanes cover 32 keys at the  \
            same 16-byte column, so that the transposed b16 LDS writes of a half-wave land  \
            in 32 consecutive halves of ONE V^T row (bank-conflict-free). */               \
@@ -169,12 +184,16 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
 
   for (int j = 0; j < n_tiles; ++j) {
     if (j + 1 < n_tiles) CRA5_KV_LOAD(j + 1);
+    ATT_SCHED();
 
     if (wave_active) {
       // ---- S^T tile (32 keys x 32 queries) -----------------------------------------------
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#ifdef ATT_SETPRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
         const half8 kh = *reinterpret_cast<const half8 *>(k_base + 16 * st);
@@ -233,6 +252,7 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
       }
     }
 
+    ATT_SCHED();
     __syncthreads();
     if (j + 1 < n_tiles) {
       CRA5_KV_STORE();
@@ -293,5 +313,8 @@ extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp
   const long ldq = 2L * qkv_kp;
   if (L % 192 == 0 && L <= 1152)
     return launch<6>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
-  return launch<4>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+#ifndef ATT_NW_GLOBAL
+#define ATT_NW_GLOBAL 4
+#endif
+  return launch<ATT_NW_GLOBAL>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
 }
