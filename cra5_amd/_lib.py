@@ -24,6 +24,16 @@ SIGNATURES = {
     "cra5_rans_decode_batch": (c_int, [c_int, P(c_void_p), P(c_size_t), P(c_void_p), P(c_size_t), P(c_void_p), P(c_int),
                                        P(c_int), P(c_void_p), P(c_void_p), P(c_void_p), P(c_int), c_int]),
     "cra5_free": (None, [c_void_p]),
+    "cra5_rans_encoder_new": (c_void_p, []),
+    "cra5_rans_encoder_push": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p,
+                                       c_void_p]),
+    "cra5_rans_encoder_flush": (c_int, [c_void_p, P(c_void_p), P(c_size_t)]),
+    "cra5_rans_encoder_free": (None, [c_void_p]),
+    "cra5_rans_decoder_new": (c_void_p, []),
+    "cra5_rans_decoder_set_stream": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "cra5_rans_decoder_decode_stream": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p,
+                                                c_void_p, c_void_p]),
+    "cra5_rans_decoder_free": (None, [c_void_p]),
     "cra5_pmf_to_quantized_cdf": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "cra5_gemm_nt_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_int, c_void_p]),

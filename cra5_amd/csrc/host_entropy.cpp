@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -162,16 +163,7 @@ struct Decoder {
   }
 };
 
-int decode_impl(const uint8_t *enc, size_t len, const int32_t *indexes, size_t n, const Tables &t,
-                int32_t *out) {
-  if ((n && (!indexes || !out)) || !enc) return CRA5_ERR_ARG;
-  if (len < 8) return CRA5_ERR_STREAM;
-  Decoder d;
-  d.p = enc;
-  d.end = enc + len;
-  const uint64_t lo = d.word();
-  const uint64_t hi = d.word();
-  d.x = lo | (hi << 32);
+int decode_symbols(Decoder &d, const int32_t *indexes, size_t n, const Tables &t, int32_t *out) {
   constexpr uint64_t mask = (1ull << kProbBits) - 1;
   for (size_t i = 0; i < n; ++i) {
     const int32_t ci = indexes[i];
@@ -207,6 +199,41 @@ int decode_impl(const uint8_t *enc, size_t len, const int32_t *indexes, size_t n
   }
   return CRA5_OK;
 }
+
+int decoder_init(Decoder &d, const uint8_t *enc, size_t len) {
+  if (!enc) return CRA5_ERR_ARG;
+  if (len < 8) return CRA5_ERR_STREAM;
+  d.p = enc;
+  d.end = enc + len;
+  d.ok = true;
+  const uint64_t lo = d.word();
+  const uint64_t hi = d.word();
+  d.x = lo | (hi << 32);  // Rans64DecInit
+  return CRA5_OK;
+}
+
+int decode_impl(const uint8_t *enc, size_t len, const int32_t *indexes, size_t n, const Tables &t,
+                int32_t *out) {
+  if (n && (!indexes || !out)) return CRA5_ERR_ARG;
+  Decoder d;
+  const int rc = decoder_init(d, enc, len);
+  if (rc) return rc;
+  return decode_symbols(d, indexes, n, t, out);
+}
+
+// ---- stateful objects: BufferedRansEncoder / RansDecoder.set_stream + decode_stream --------
+struct BufferedSym {
+  uint16_t start, range;
+  bool bypass;
+};
+struct BufferedEncoder {
+  std::vector<BufferedSym> syms;  // forward order, like the reference's _syms (rans_interface.cpp:142-170)
+};
+struct StreamDecoder {
+  std::vector<uint8_t> stream;
+  Decoder d;
+  bool ready = false;
+};
 
 template <class F>
 void parallel_for(int n, int n_threads, F &&f) {
@@ -276,6 +303,94 @@ int cra5_rans_decode_batch(int n_streams, const uint8_t *const *encoded, const s
 }
 
 void cra5_free(void *p) { std::free(p); }
+
+/* BufferedRansEncoder (rans_interface.cpp:108-200): symbols of several calls (possibly with
+ * different tables) are buffered, flush() codes them all in reverse into one stream. */
+void *cra5_rans_encoder_new(void) { return new (std::nothrow) BufferedEncoder(); }
+void cra5_rans_encoder_free(void *enc) { delete static_cast<BufferedEncoder *>(enc); }
+
+int cra5_rans_encoder_push(void *enc, const int32_t *symbols, const int32_t *indexes, size_t n,
+                           const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                           const int32_t *offsets) {
+  if (!enc || !cdfs || !cdf_sizes || !offsets || n_cdfs <= 0 || cdf_stride < 2 || (n && (!symbols || !indexes)))
+    return CRA5_ERR_ARG;
+  auto *e = static_cast<BufferedEncoder *>(enc);
+  const Tables t{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets};
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t ci = indexes[i];
+    if (ci < 0 || ci >= n_cdfs || cdf_sizes[ci] < 2 || cdf_sizes[ci] > cdf_stride) return CRA5_ERR_INDEX;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const Resolved r = resolve(t, symbols[i], indexes[i]);
+    e->syms.push_back({static_cast<uint16_t>(r.start), static_cast<uint16_t>(r.range), false});
+    if (r.escape) {
+      uint32_t val = static_cast<uint32_t>(r.n_nibbles);
+      while (val >= kBypassMax) {
+        e->syms.push_back({static_cast<uint16_t>(kBypassMax), static_cast<uint16_t>(kBypassMax + 1), true});
+        val -= kBypassMax;
+      }
+      e->syms.push_back({static_cast<uint16_t>(val), static_cast<uint16_t>(val + 1), true});
+      for (int j = 0; j < r.n_nibbles; ++j) {
+        const uint32_t v = (r.raw >> (j * kBypassBits)) & kBypassMax;
+        e->syms.push_back({static_cast<uint16_t>(v), static_cast<uint16_t>(v + 1), true});
+      }
+    }
+  }
+  return CRA5_OK;
+}
+
+int cra5_rans_encoder_flush(void *enc, uint8_t **out, size_t *out_len) {
+  if (!enc || !out || !out_len) return CRA5_ERR_ARG;
+  auto *e = static_cast<BufferedEncoder *>(enc);
+  const size_t cap = e->syms.size() + 2;
+  uint32_t *buf = static_cast<uint32_t *>(std::malloc(cap * sizeof(uint32_t)));
+  if (!buf) return CRA5_ERR_ALLOC;
+  Encoder c;
+  c.ptr = buf + cap;
+  for (size_t k = e->syms.size(); k-- > 0;) {
+    const BufferedSym &s = e->syms[k];
+    if (!s.bypass) c.put(s.start, s.range);
+    else c.put_bits(s.start);
+  }
+  c.ptr -= 2;
+  c.ptr[0] = static_cast<uint32_t>(c.x);
+  c.ptr[1] = static_cast<uint32_t>(c.x >> 32);
+  const size_t nbytes = static_cast<size_t>((buf + cap) - c.ptr) * sizeof(uint32_t);
+  uint8_t *res = static_cast<uint8_t *>(std::malloc(nbytes));
+  if (!res) {
+    std::free(buf);
+    return CRA5_ERR_ALLOC;
+  }
+  std::memcpy(res, c.ptr, nbytes);
+  std::free(buf);
+  e->syms.clear();
+  *out = res;
+  *out_len = nbytes;
+  return CRA5_OK;
+}
+
+/* RansDecoder.set_stream / decode_stream (rans_interface.cpp:286-359): the decoder keeps its
+ * state between calls, so one stream can be decoded in several pieces with different tables. */
+void *cra5_rans_decoder_new(void) { return new (std::nothrow) StreamDecoder(); }
+void cra5_rans_decoder_free(void *dec) { delete static_cast<StreamDecoder *>(dec); }
+
+int cra5_rans_decoder_set_stream(void *dec, const uint8_t *encoded, size_t len) {
+  if (!dec || !encoded) return CRA5_ERR_ARG;
+  auto *d = static_cast<StreamDecoder *>(dec);
+  d->stream.assign(encoded, encoded + len);
+  const int rc = decoder_init(d->d, d->stream.data(), d->stream.size());
+  d->ready = (rc == CRA5_OK);
+  return rc;
+}
+
+int cra5_rans_decoder_decode_stream(void *dec, const int32_t *indexes, size_t n, const int32_t *cdfs, int n_cdfs,
+                                    int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out) {
+  if (!dec || !cdfs || !cdf_sizes || !offsets || n_cdfs <= 0 || cdf_stride < 2 || (n && (!indexes || !out)))
+    return CRA5_ERR_ARG;
+  auto *d = static_cast<StreamDecoder *>(dec);
+  if (!d->ready) return CRA5_ERR_STREAM;
+  return decode_symbols(d->d, indexes, n, Tables{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets}, out);
+}
 
 int cra5_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf) {
   if (!pmf || !cdf || n <= 0 || precision < 1 || precision > 16) return CRA5_ERR_ARG;

@@ -71,6 +71,24 @@ int cra5_rans_decode_batch(int n_streams, const uint8_t *const *encoded, const s
 
 void cra5_free(void *p);
 
+/* Stateful forms of the same coder (class decls rans_interface.hpp:49-113):
+ *   BufferedRansEncoder: push() any number of (symbols, indexes, tables) groups, then flush()
+ *   codes them all - last pushed symbol first - into ONE stream (rans_interface.cpp:108-200);
+ *   RansDecoder.set_stream()/decode_stream(): the decoder keeps its state between calls
+ *   (rans_interface.cpp:286-359).  Handles are not thread-safe; use one per thread. */
+void *cra5_rans_encoder_new(void);
+int cra5_rans_encoder_push(void *enc, const int32_t *symbols, const int32_t *indexes, size_t n,
+                           const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                           const int32_t *cdf_sizes, const int32_t *offsets);
+int cra5_rans_encoder_flush(void *enc, uint8_t **out, size_t *out_len);
+void cra5_rans_encoder_free(void *enc);
+void *cra5_rans_decoder_new(void);
+int cra5_rans_decoder_set_stream(void *dec, const uint8_t *encoded, size_t len);
+int cra5_rans_decoder_decode_stream(void *dec, const int32_t *indexes, size_t n, const int32_t *cdfs,
+                                    int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                    const int32_t *offsets, int32_t *out);
+void cra5_rans_decoder_free(void *dec);
+
 /* pmf_to_quantized_cdf (ops.cpp:40-108). cdf has n+1 slots. */
 int cra5_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf);
 

@@ -312,3 +312,16 @@ def test_gdn_golden(dev, golden_dir):
         gamma = torch.clamp(gamma_p, min=ped ** 0.5) ** 2 - ped
         y = ops.gdn(x.to(dev), beta.to(dev), gamma.contiguous().to(dev), inverse=bool(inv))
         assert rmse(y, torch.from_numpy(d[f"gdn_inv{inv}_y"])) < 1e-6
+
+
+def test_gdn_module_state_dict_and_forward(dev, golden_dir):
+    from cra5_amd.layers import GDN
+    d = np.load(f"{golden_dir}/ops_small.npz")
+    for inv in (0, 1):
+        m = GDN(12, inverse=bool(inv))
+        assert set(m.state_dict()) == {"beta", "gamma", "beta_reparam.pedestal", "beta_reparam.lower_bound.bound",
+                                       "gamma_reparam.pedestal", "gamma_reparam.lower_bound.bound"}
+        m.beta.data = torch.from_numpy(d[f"gdn_inv{inv}_beta"])
+        m.gamma.data = torch.from_numpy(d[f"gdn_inv{inv}_gamma"])
+        y = m.to(dev)(torch.from_numpy(d[f"gdn_inv{inv}_x"]).to(dev))
+        assert rmse(y, torch.from_numpy(d[f"gdn_inv{inv}_y"])) < 1e-6

@@ -132,3 +132,36 @@ def test_product_pmf_to_cdf_matches_reference(golden_dir):
         if e["raises"]:
             with pytest.raises(ValueError):  # std::domain_error -> ValueError in the reference binding
                 ops.pmf_to_quantized_cdf(np.array([float(v) for v in e["pmf"]], dtype=np.float32))
+
+
+def test_stateful_classes_match_reference_semantics():
+    """cra5_amd.ans: BufferedRansEncoder (several pushes with DIFFERENT tables, one flush) and
+    RansDecoder.set_stream/decode_stream, against the pure-Python oracle of the same classes."""
+    from cra5_amd import ans
+    rng = np.random.default_rng(11)
+    ta = _random_tables(rng, 3, 20)
+    tb = _random_tables(rng, 5, 40)
+    groups = []
+    for t in (ta, tb, ta):
+        n = int(rng.integers(1, 800))
+        groups.append((rng.integers(-60, 60, size=n).astype(np.int32),
+                       rng.integers(0, t[0].shape[0], size=n).astype(np.int32), t))
+    e, eo = ans.BufferedRansEncoder(), rans_py.BufferedRansEncoder()
+    for sym, idx, (cdf, lens, offs) in groups:
+        e.encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
+        eo.encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
+    stream = e.flush()
+    assert stream == eo.flush()
+    assert e.flush() == eo.flush()          # flushing an empty encoder: just the 8-byte state
+    d, do = ans.RansDecoder(), rans_py.RansDecoder()
+    d.set_stream(stream)
+    do.set_stream(stream)
+    for sym, idx, (cdf, lens, offs) in groups:
+        got = d.decode_stream(idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
+        assert got == sym.tolist() == do.decode_stream(idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
+    # one-shot classes
+    sym, idx, (cdf, lens, offs) = groups[1]
+    s1 = ans.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
+    assert s1 == rans_py.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
+    assert ans.RansDecoder().decode_with_indexes(s1, idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist()) == sym.tolist()
+    assert ans.pmf_to_quantized_cdf([0.25, 0.5, 0.25], 16) == [0, 16384, 49152, 65536]
