@@ -325,3 +325,28 @@ def test_gdn_module_state_dict_and_forward(dev, golden_dir):
         m.gamma.data = torch.from_numpy(d[f"gdn_inv{inv}_gamma"])
         y = m.to(dev)(torch.from_numpy(d[f"gdn_inv{inv}_x"]).to(dev))
         assert rmse(y, torch.from_numpy(d[f"gdn_inv{inv}_y"])) < 1e-6
+
+
+@pytest.mark.parametrize("C", [8, 7, 13])
+def test_tiled_patch_gather_scatter_matches_generic(dev, C):
+    """The LDS-tiled ERA5-geometry kernels (taken for k=(11,10), s=(10,10)) against torch
+    unfold / fold, incl. a ragged last channel chunk, fused (de)normalisation and split output."""
+    g = torch.Generator().manual_seed(40 + C)
+    H, W = 721, 1440
+    x = torch.randn(C, H, W, generator=g)
+    mean = torch.randn(C, generator=g)
+    std = torch.rand(C, generator=g) + 0.5
+    K = C * 110
+    Kp = (K + 31) // 32 * 32
+    xn = (x - mean[:, None, None]) / std[:, None, None]
+    ref = torch.nn.functional.unfold(xn[None], (11, 10), stride=(10, 10))[0].t().contiguous()
+    cols = ops.im2col(x.to(dev), 11, 10, 10, 10, ldk=Kp, mean=mean.to(dev), std=std.to(dev))
+    assert torch.equal(cols[:, :K].cpu(), ref) and torch.count_nonzero(cols[:, K:]) == 0
+    sm = ops.SplitMat.empty(72 * 144, K, dev, zero=True)
+    ops.im2col(x.to(dev), 11, 10, 10, 10, mean=mean.to(dev), std=std.to(dev), out_split=sm)
+    assert float((sm.to_float().cpu() - ref).abs().max()) <= 2 ** -21 * float(ref.abs().max()) + 2 ** -24
+    back = ops.col2im(cols[:, :K], C, 11, 10, 10, 10, 72, 144, mean=mean.to(dev), std=std.to(dev))
+    ref_back = torch.nn.functional.fold(ref.t()[None], (H, W), (11, 10), stride=(10, 10))[0]
+    assert rmse(back, ref_back * std[:, None, None] + mean[:, None, None]) < 1e-6
+    raw = ops.col2im(cols[:, :K], C, 11, 10, 10, 10, 72, 144)
+    assert torch.equal(raw.cpu(), ref_back)   # two-term sums: bit-exact
