@@ -54,8 +54,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   return base + within;
 }
 
-template <int WM, int WN, int TM, int TN, bool LONGK>
-__global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2>
+__global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_split_kernel(
     const unsigned short *__restrict__ A, long lda, const unsigned short *__restrict__ W, long ldw, float *C,
     int ldc, unsigned short *Cs, long ldcs, const float *__restrict__ bias, const float *res, int ldr, int M,
     int N, int Kp, float wscale_inv, int flags, int tiles_n) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
   // two stages of [A hi][A lo][W hi][W lo]; rows are 64 B (4 x 16-byte pieces), piece p of row r
   // lives at physical piece p ^ ((r >> 2) & 3): every ds_read_b128 lane group (16 rows, one
   // logical piece) then touches 16 distinct 16-byte slots - conflict-free without padding.
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE];
 
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = pid / tiles_n, tn = pid % tiles_n;
@@ -145,14 +145,20 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
   const int nk = Kp / BK;
   CRA5_GLOAD(0);
   CRA5_SSTORE(0);
-  if (nk > 1) CRA5_GLOAD(1);
+  if (STAGES == 2 && nk > 1) CRA5_GLOAD(1);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    // tile kt+1 (in registers since the previous step) -> the other stage, then prefetch kt+2
-    if (kt + 1 < nk) CRA5_SSTORE(cur ^ 1);
-    if (kt + 2 < nk) CRA5_GLOAD(kt + 2);
+    const int cur = (STAGES == 2) ? (kt & 1) : 0;
+    if (STAGES == 2) {
+      // tile kt+1 (in registers since the previous step) -> the other stage, then prefetch kt+2
+      if (kt + 1 < nk) CRA5_SSTORE(cur ^ 1);
+      if (kt + 2 < nk) CRA5_GLOAD(kt + 2);
+    } else {
+      // single stage (two co-resident blocks per CU cover each other's barriers / epilogues):
+      // fetch tile kt+1 into registers while tile kt is consumed
+      if (kt + 1 < nk) CRA5_GLOAD(kt + 1);
+    }
     const unsigned short *st = lds + cur * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -195,7 +201,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_nt_split_kernel(
             acc[i][j][r] = 0.f;
           }
     }
-    __syncthreads();   // stage cur fully consumed, stage cur^1 fully written
+    __syncthreads();   // stage cur fully consumed (STAGES == 2: and stage cur^1 fully written)
+    if (STAGES == 1 && kt + 1 < nk) {
+      CRA5_SSTORE(0);
+      __syncthreads();
+    }
   }
 
   const bool has_bias = flags & CRA5_EPI_BIAS;
@@ -256,13 +266,13 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool LONGK>
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2>
 int launch(const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C, int ldc,
            unsigned short *Cs, long ldcs, const float *bias, const float *res, int ldr, int M, int N, int Kp,
            float wscale_inv, int flags, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
+  hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK, STAGES>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
                      st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n);
   return (int)hipGetLastError();
 }
@@ -293,6 +303,10 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
   if (tile == 64) CRA5_GO(2, 2, 1, 1, false);
   if (tile == 192) CRA5_GO(2, 4, 3, 2, false);   // 192 x 256, 8 waves (2 x 4), 3 x 2 sub-tiles per wave
   if (tile == 256) CRA5_GO(2, 4, 4, 2, false);   // 256 x 256, 8 waves (2 x 4), 4 x 2 sub-tiles per wave
+  if (tile == 1282)   // 128 x 256, 4 waves (2 x 2), 2 x 4 sub-tiles per wave, single LDS stage: 2 blocks / CU
+    return launch<2, 2, 2, 4, false, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+  if (tile == 2561)   // 256 x 128, 4 waves, 4 x 2 sub-tiles per wave, single stage
+    return launch<2, 2, 4, 2, false, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
   CRA5_GO(2, 2, 2, 2, false);
 #undef CRA5_GO
 }
