@@ -239,7 +239,10 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    pipe.close()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
