@@ -56,7 +56,7 @@ constexpr int HD = 64;
 constexpr int KS = 72;   // K LDS row stride (halves): 144 B
 constexpr int VS = 36;   // V^T LDS row stride (halves): 72 B
 
-template <int NW>
+template <int NW, bool HI>
 __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
     const unsigned short *__restrict__ qkv, long ldq /* halves per row = 2*Kp */,
     const unsigned short *__restrict__ pad_row, float *__restrict__ out, unsigned short *__restrict__ out_s,
@@ -198,8 +198,10 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
       for (int st = 0; st < 4; ++st) {
         const half8 kh = *reinterpret_cast<const half8 *>(k_base + 16 * st);
         const half8 kl = *reinterpret_cast<const half8 *>(k_base + KPL + 16 * st);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
+        if (!HI) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
+        }
         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
       }
       // ---- online softmax, log2 domain ---------------------------------------------------
@@ -243,10 +245,12 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
           vh[dt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
           vl[dt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[0], ph[t], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[1], ph[t], o[1], 0, 0, 0);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], pl[t], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], pl[t], o[1], 0, 0, 0);
+        if (!HI) {
+          o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[0], ph[t], o[0], 0, 0, 0);
+          o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[1], ph[t], o[1], 0, 0, 0);
+          o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], pl[t], o[0], 0, 0, 0);
+          o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], pl[t], o[1], 0, 0, 0);
+        }
         o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], ph[t], o[0], 0, 0, 0);
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], ph[t], o[1], 0, 0, 0);
       }
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
   }
 }
 
-template <int NW>
+template <int NW, bool HI>
 int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, float *out, unsigned short *out_s,
            int Kp_out, int C, int heads, int H, int W, int wh, int ww, float scale, hipStream_t st) {
   WinGeom g;
@@ -293,7 +297,7 @@ int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, f
   g.nwc = (W + ww - 1) / ww;
   const int L = wh * ww;
   const int q_tiles = (L + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL((window_attention_split_kernel<NW>), dim3(q_tiles * nwr * g.nwc * heads), dim3(NW * 64), 0, st,
+  hipLaunchKernelGGL((window_attention_split_kernel<NW, HI>), dim3(q_tiles * nwr * g.nwc * heads), dim3(NW * 64), 0, st,
                      qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, q_tiles, scale);
   return (int)hipGetLastError();
 }
@@ -302,7 +306,7 @@ int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, f
 
 extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
                                            float *out, uint16_t *out_split, int out_kp, int C, int heads, int H,
-                                           int W, int wh, int ww, float scale, void *stream) {
+                                           int W, int wh, int ww, float scale, int hi_only, void *stream) {
   if (!qkv_split || !pad_row_split || (!out && !out_split) || heads <= 0 || C % heads) return CRA5_ERR_ARG;
   if (C / heads != 64 || qkv_kp != 3 * C) return CRA5_ERR_ARG;  // head slices must be chunk-aligned
   if (wh <= 0 || ww <= 0 || H <= 0 || W <= 0 || (wh * ww) % 32) return CRA5_ERR_ARG;
@@ -311,10 +315,15 @@ extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp
   hipStream_t st = (hipStream_t)stream;
   const int L = wh * ww;
   const long ldq = 2L * qkv_kp;
+  if (hi_only) {
+    if (L % 192 == 0 && L <= 1152)
+      return launch<6, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+    return launch<4, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+  }
   if (L % 192 == 0 && L <= 1152)
-    return launch<6>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+    return launch<6, false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
 #ifndef ATT_NW_GLOBAL
 #define ATT_NW_GLOBAL 4
 #endif
-  return launch<ATT_NW_GLOBAL>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+  return launch<ATT_NW_GLOBAL, false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
 }

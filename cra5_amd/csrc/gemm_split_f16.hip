@@ -43,8 +43,24 @@ namespace {
 constexpr int BK = 32;         // elements per k-step
 constexpr int ROW_H = 32;      // LDS row = 64 B = 4 x 16-byte pieces (XOR-swizzled, no padding)
 
+// gelu(x) = x * Phi(x),  Phi(x) = 0.5 erfc(-x / sqrt 2),  erfc(t) = exp(-t^2) * k P(k), k = 1/(1 + 0.4 t)
+// for t >= 0 (degree-7 least-squares fit, |erfc error| <= 8.3e-9 on [0, 6]; evaluated in fp32 the
+// gelu error against fp64 is 1.1e-7 RMS / 6.1e-7 max over [-9, 9] - below torch's own fp32
+// erf-based gelu, 1.7e-7 / 1.3e-6; tests/test_kernels_gpu.py pins it).  One rcp + one exp2 + 10 FMAs,
+// branch-free: the libm erff costs ~3x as much with both of its branches live in a wave.
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float t = __builtin_fabsf(x) * 0.70710678118654752440f;
+  const float k = __builtin_amdgcn_rcpf(__builtin_fmaf(0.4f, t, 1.0f));
+  float p = 0.03080804832279682f;
+  p = __builtin_fmaf(p, k, -0.3524225652217865f);
+  p = __builtin_fmaf(p, k, 1.0205539464950562f);
+  p = __builtin_fmaf(p, k, -0.7088391780853271f);
+  p = __builtin_fmaf(p, k, 0.6733116507530212f);
+  p = __builtin_fmaf(p, k, 0.0958886444568634f);
+  p = __builtin_fmaf(p, k, 0.2406993806362152f);
+  const float half_erfc = 0.5f * p * k * __builtin_amdgcn_exp2f(-(t * t) * 1.4426950408889634f);
+  const float phi = (x >= 0.f) ? 1.0f - half_erfc : half_erfc;
+  return x * phi;
 }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nb) {
@@ -54,7 +70,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   return base + within;
 }
 
-template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2>
+#ifdef CRA5_GEMM_TRACE
+// debug build only (tools/gemm_trace.py): per-block timestamps {entry, main loop start, main loop
+// end, exit} from the 100 MHz wall clock, + the hardware id register.
+__device__ unsigned long long g_gemm_trace[5 * 8192];
+#define CRA5_TRACE(slot)                                                        \
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 5 + (slot)] = wall_clock64();
+#else
+#define CRA5_TRACE(slot)
+#endif
+
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3>
 __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_split_kernel(
     const unsigned short *__restrict__ A, long lda, const unsigned short *__restrict__ W, long ldw, float *C,
     int ldc, unsigned short *Cs, long ldcs, const float *__restrict__ bias, const float *res, int ldr, int M,
@@ -73,6 +99,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   // logical piece) then touches 16 distinct 16-byte slots - conflict-free without padding.
   __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE];
 
+  CRA5_TRACE(0);
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = pid / tiles_n, tn = pid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -147,6 +174,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   CRA5_SSTORE(0);
   if (STAGES == 2 && nk > 1) CRA5_GLOAD(1);
   __syncthreads();
+  CRA5_TRACE(1);
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = (STAGES == 2) ? (kt & 1) : 0;
@@ -166,24 +194,27 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const half8 *>(st + a_row + i * 32 * ROW_H + poff[kk]);
-        al[i] = *reinterpret_cast<const half8 *>(st + a_row + BM * ROW_H + i * 32 * ROW_H + poff[kk]);
+        if (NPROD == 3) al[i] = *reinterpret_cast<const half8 *>(st + a_row + BM * ROW_H + i * 32 * ROW_H + poff[kk]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const half8 *>(st + b_row + j * 32 * ROW_H + poff[kk]);
-        bl[j] = *reinterpret_cast<const half8 *>(st + b_row + BN * ROW_H + j * 32 * ROW_H + poff[kk]);
+        if (NPROD == 3) bl[j] = *reinterpret_cast<const half8 *>(st + b_row + BN * ROW_H + j * 32 * ROW_H + poff[kk]);
       }
-      // small terms first, plane-major: TM*TN independent accumulators between dependent MFMAs
+      // small terms first, plane-major: TM*TN independent accumulators between dependent MFMAs.
+      // NPROD == 1 is the reduced-precision mode (BASELINE.json configs[4]): hi.hi only = plain f16.
+      if (NPROD == 3) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -208,50 +239,110 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
     }
   }
 
+  CRA5_TRACE(2);
   const bool has_bias = flags & CRA5_EPI_BIAS;
   const bool do_gelu = flags & CRA5_EPI_GELU;
   const bool has_res = flags & CRA5_EPI_RES;
+
+  // Epilogue through wave-private LDS (the pipeline stages are free after the last barrier):
+  // a wave parks one 32 x (TN*32) row block of accumulators, reads it back row-contiguous, 4
+  // columns per lane, and applies scale / bias / GELU / residual on float4s: 16-byte residual
+  // loads and fp32 stores, 8-byte packed hi / lo stores of the split layout - 8 memory
+  // instructions per 32 rows instead of 32-64 dword ones.
+  constexpr int COLS = TN * 32;
+  constexpr int LDW = COLS + 4;          // floats; +4 keeps rows 16-byte aligned and shifts banks
+  constexpr int LPR = COLS / 4;          // lanes per row
+  constexpr int RPI = 64 / LPR;          // rows per wave-instruction
+  static_assert((size_t)WM * WN * 32 * LDW * 4 <= sizeof(lds), "epilogue staging does not fit the stages");
+  float *stg = reinterpret_cast<float *>(lds) + wave * 32 * LDW;
+  const int er = lane / LPR, ec = (lane % LPR) * 4;
+  const int nw = n0 + wn * COLS + ec;    // first of this lane's 4 columns
+  const bool vecC = C && ((ldc & 3) == 0) && ((reinterpret_cast<size_t>(C) & 15) == 0);
+  const bool vecR = has_res && ((ldr & 3) == 0) && ((reinterpret_cast<size_t>(res) & 15) == 0);
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (has_bias) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + l31;
-    if (n0 + (wn * TN + j) * 32 >= N) continue;   // wave-uniform (the shuffle below needs all lanes)
-    const float bv = (has_bias && n < N) ? bias[n] : 0.f;
+    for (int c = 0; c < 4; ++c)
+      if (nw + c < N) bv[c] = bias[nw + c];
+  }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + (wm * TM + i) * 32 + 4 * h;
-      float vout[16];
+  for (int i = 0; i < TM; ++i) {
+    const int mrow0 = m0 + (wm * TM + i) * 32;
+    if (mrow0 >= M) break;               // wave-uniform
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        vout[r] = 0.f;
-        if (m < M && n < N) {
-          float v = acc[i][j][r];
-          if (LONGK) v += master[i][j][r];
-          v = v * wscale_inv + bv;
-          if (do_gelu) v = gelu_erf(v);
-          if (has_res) v += res[(size_t)m * ldr + n];
-          vout[r] = v;
-          if (C) C[(size_t)m * ldc + n] = v;
-        }
-        if (Cs) {
-          // split-f16 store, 4 bytes per lane: lane pairs (2i, 2i+1) hold adjacent columns;
-          // the even lane stores the packed hi pair, the odd lane the packed lo pair ->
-          // one full 128-byte chunk [32 hi | 32 lo] per row per half-wave.
-          const _Float16 hi = (_Float16)vout[r];
-          const _Float16 lo = (_Float16)(vout[r] - (float)hi);
-          const unsigned int mine = (unsigned int)__builtin_bit_cast(unsigned short, hi) |
-                                    ((unsigned int)__builtin_bit_cast(unsigned short, lo) << 16);
-          const unsigned int other = (unsigned int)__shfl_xor((int)mine, 1, 64);
-          const bool odd = lane & 1;
-          // even: (hi_own, hi_next)   odd: (lo_prev, lo_own)
-          const unsigned int word = odd ? ((other >> 16) | (mine & 0xFFFF0000u)) : ((mine & 0xFFFFu) | (other << 16));
-          const int nn = n & ~1;
-          if (m < M && nn + 1 < ((N + 1) & ~1))
-            *reinterpret_cast<unsigned int *>(Cs + (size_t)m * ldcs + (nn >> 5) * 64 + (odd ? 32 : 0) + (nn & 31)) = word;
+        float v = acc[i][j][r];
+        if (LONGK) v += master[i][j][r];
+        stg[(4 * h + (r & 3) + 8 * (r >> 2)) * LDW + j * 32 + l31] = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    float4 v4[32 / RPI];
+#pragma unroll
+    for (int p = 0; p < 32 / RPI; ++p) v4[p] = *reinterpret_cast<const float4 *>(stg + (p * RPI + er) * LDW + ec);
+    __builtin_amdgcn_wave_barrier();
+    float4 r4[32 / RPI];
+    if (has_res) {
+#pragma unroll
+      for (int p = 0; p < 32 / RPI; ++p) {
+        const int m = mrow0 + p * RPI + er;
+        r4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && nw < N) {
+          const float *rp = res + (size_t)m * ldr + nw;
+          if (vecR && nw + 3 < N) {
+            r4[p] = *reinterpret_cast<const float4 *>(rp);
+          } else {
+            r4[p].x = rp[0];
+            if (nw + 1 < N) r4[p].y = rp[1];
+            if (nw + 2 < N) r4[p].z = rp[2];
+            if (nw + 3 < N) r4[p].w = rp[3];
+          }
         }
       }
     }
+#pragma unroll
+    for (int p = 0; p < 32 / RPI; ++p) {
+      const int m = mrow0 + p * RPI + er;
+      if (m >= M || nw >= N) continue;
+      float o[4] = {v4[p].x, v4[p].y, v4[p].z, v4[p].w};
+      const float rr[4] = {r4[p].x, r4[p].y, r4[p].z, r4[p].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = o[c] * wscale_inv + bv[c];
+        if (do_gelu) v = gelu_erf(v);
+        if (has_res) v += rr[c];
+        o[c] = (nw + c < N) ? v : 0.f;
+      }
+      if (C) {
+        float *cp = C + (size_t)m * ldc + nw;
+        if (vecC && nw + 3 < N) {
+          *reinterpret_cast<float4 *>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          cp[0] = o[0];
+          if (nw + 1 < N) cp[1] = o[1];
+          if (nw + 2 < N) cp[2] = o[2];
+          if (nw + 3 < N) cp[3] = o[3];
+        }
+      }
+      if (Cs) {
+        // split layout: 128-byte chunk per 32 columns = [32 hi | 32 lo]; 4 columns -> 8 B + 8 B.
+        // Columns >= N inside the group are written as zero (they are K padding of the consumer).
+        unsigned short hi[4], lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const _Float16 hh = (_Float16)o[c];
+          const _Float16 ll = (_Float16)(o[c] - (float)hh);
+          hi[c] = __builtin_bit_cast(unsigned short, hh);
+          lo[c] = __builtin_bit_cast(unsigned short, ll);
+        }
+        unsigned short *sp = Cs + (size_t)m * ldcs + (nw >> 5) * 64 + (nw & 31);
+        *reinterpret_cast<uint2 *>(sp) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+        *reinterpret_cast<uint2 *>(sp + 32) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+      }
+    }
   }
+  CRA5_TRACE(3);
 }
 
 // fp32 [rows][K] (row stride ldx) -> split-f16 [rows][2*Kp] halves, x * scale, pad zeros.
@@ -266,13 +357,13 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2>
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3>
 int launch(const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C, int ldc,
            unsigned short *Cs, long ldcs, const float *bias, const float *res, int ldr, int M, int N, int Kp,
            float wscale_inv, int flags, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK, STAGES>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
+  hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK, STAGES, NPROD>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
                      st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n);
   return (int)hipGetLastError();
 }
@@ -291,6 +382,14 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
   }();
   const bool longk = Kp > 8192;
   if (longk) CRA5_GO(2, 2, 2, 2, true);
+  if (flags & CRA5_GEMM_HI_ONLY) {   // reduced precision: one f16 MFMA per product
+    const bool wide = (M >= 1024 && N >= 2048);
+    if (tiles128 < 256)
+      return launch<2, 2, 1, 1, false, 2, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+    if (wide)
+      return launch<2, 4, 4, 2, false, 2, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+    return launch<2, 4, 3, 2, false, 2, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+  }
   int tile = forced;
   if (!tile) {
     // measured on MI355X (tools/gemm_bench.py, M = 10368): N = 1024 (proj, fc2, patch-embed):
@@ -303,10 +402,6 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
   if (tile == 64) CRA5_GO(2, 2, 1, 1, false);
   if (tile == 192) CRA5_GO(2, 4, 3, 2, false);   // 192 x 256, 8 waves (2 x 4), 3 x 2 sub-tiles per wave
   if (tile == 256) CRA5_GO(2, 4, 4, 2, false);   // 256 x 256, 8 waves (2 x 4), 4 x 2 sub-tiles per wave
-  if (tile == 1282)   // 128 x 256, 4 waves (2 x 2), 2 x 4 sub-tiles per wave, single LDS stage: 2 blocks / CU
-    return launch<2, 2, 2, 4, false, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
-  if (tile == 2561)   // 256 x 128, 4 waves, 4 x 2 sub-tiles per wave, single stage
-    return launch<2, 2, 4, 2, false, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
   CRA5_GO(2, 2, 2, 2, false);
 #undef CRA5_GO
 }
@@ -331,7 +426,7 @@ extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t 
     const int per = ((Kp / 32 + nchunk - 1) / nchunk) * 32;
     for (int k0 = 0, i = 0; k0 < Kp; k0 += per, ++i) {
       const int kc = (Kp - k0 < per) ? Kp - k0 : per;
-      const int f = (i == 0) ? flags : CRA5_EPI_RES;
+      const int f = ((i == 0) ? flags : CRA5_EPI_RES) | (flags & CRA5_GEMM_HI_ONLY);
       const int rc = gemm_dispatch(A + 2L * k0, lda, W + 2L * k0, ldw, C, ldc, nullptr, 0, (i == 0) ? bias : nullptr,
                                    (i == 0) ? res : C, (i == 0) ? ldr : ldc, M, N, kc, wscale_inv, f, st);
       if (rc) return rc;
@@ -351,3 +446,15 @@ extern "C" int cra5_split_f16(const float *x, int ldx, uint16_t *out, int rows, 
                      K, Kp, scale);
   return (int)hipGetLastError();
 }
+
+#ifdef CRA5_GEMM_TRACE
+extern "C" int cra5_debug_gemm_trace(unsigned long long *host, int n_blocks) {
+  if (n_blocks > 8192) n_blocks = 8192;
+  hipDeviceSynchronize();
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 5 * n_blocks);
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gemm_trace)) == hipSuccess) hipMemset(p, 0, sizeof(unsigned long long) * 5 * 8192);
+  hipDeviceSynchronize();
+  return rc;
+}
+#endif

@@ -8,7 +8,7 @@ import torch
 
 from ._lib import check, lib
 
-EPI_BIAS, EPI_GELU, EPI_RES = 1, 2, 4
+EPI_BIAS, EPI_GELU, EPI_RES, GEMM_HI_ONLY = 1, 2, 4, 8
 
 
 def _stream():
@@ -149,7 +149,7 @@ def split_f16(x, scale_pow2=None, out=None):
     return out
 
 
-def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True):
+def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True, hi_only=False):
     """epi(a @ w^T) with a, w SplitMat (same K).  out: fp32 [M, N] (row-strided ok) unless
     want_f32=False; out_split: SplitMat [M, N] to receive the split-f16 result."""
     _devs(a.data, w.data)
@@ -162,6 +162,8 @@ def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=Non
     if out_split is not None:
         assert out_split.rows == M and out_split.K == N
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
+    if hi_only:
+        flags |= GEMM_HI_ONLY
     ev = TIMER.start() if TIMER is not None else None
     check(lib().cra5_gemm_nt_split(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
                                    _row_stride(out) if out is not None else 0,
@@ -214,7 +216,7 @@ def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None, out_split=None
     return out if out is not None else out_split
 
 
-def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None):
+def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None, hi_only=False):
     """qkv_s: SplitMat [H*W, 3C]; pad_s: SplitMat [1, 3C] (the split qkv bias)."""
     _devs(qkv_s.data, pad_s.data)
     _dev(out)
@@ -227,7 +229,7 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
     check(lib().cra5_window_attention_split(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
                                             _p(out_split.data) if out_split is not None else None,
                                             out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
-                                            scale, _stream()), "cra5_window_attention_split")
+                                            scale, int(bool(hi_only)), _stream()), "cra5_window_attention_split")
     if ev is not None:
         TIMER.stop("window_attention_split", ev, 4.0 * N * (wh * ww) * C)
     return out if out is not None else out_split

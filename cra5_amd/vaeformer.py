@@ -264,6 +264,13 @@ class VAEformer(nn.Module):
         self.gemm_mode = os.environ.get("CRA5_GEMM", "split")
         if self.gemm_mode not in ("split", "f32"):
             raise ValueError("CRA5_GEMM must be 'split' or 'f32'")
+        # "fp32" (default): 3-product split, fp32-accurate.  "f16": BASELINE.json configs[4] -
+        # g_a / g_s projections and attention use plain f16 operands (1 MFMA per product, fp32
+        # accumulate); the hyper-prior / GaussianConditional side stays fp32-accurate so that
+        # encoder and decoder derive identical CDF indexes.  RMSE-gated in tests/test_model_gpu.py.
+        self.precision = os.environ.get("CRA5_PRECISION", "fp32")
+        if self.precision not in ("fp32", "f16"):
+            raise ValueError("CRA5_PRECISION must be 'fp32' or 'f16'")
         self._derived = {}
         self._derive_lock = threading.RLock()
         self._gpu_lock = threading.Lock()
@@ -404,11 +411,12 @@ class VAEformer(nn.Module):
         epilogue, no fp32 copy; f32 engine: a named fp32 workspace)."""
         if self.gemm_mode == "split":
             W = self._wsplit(key, w)
+            hi = self.precision == "f16" and key.startswith(("g_a.", "g_s."))
             if out_name is not None:
                 sm = self._sbuf(out_name, a.rows, W.rows)
-                ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False)
+                ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False, hi_only=hi)
                 return sm
-            return ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out=out)
+            return ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out=out, hi_only=hi)
         W = self._wf32(key, w, pad32=(a.shape[1] % 32 == 0 and self._weight2d(key, w).shape[1] != a.shape[1]))
         if out_name is not None:
             out = self._buf(out_name, (a.shape[0], W.shape[0]))
@@ -428,7 +436,8 @@ class VAEformer(nn.Module):
             qkv_s = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out_name=f"qkv{D}")
             pad_s = self._derive("pad." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)))
             att = self._sbuf(f"att{D}", N, D, zero=True)
-            ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att)
+            ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att,
+                                       hi_only=self.precision == "f16" and pre.startswith(("g_a.", "g_s.")))
             self._mm(att, pre + ".attn.proj", blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
             h = self._ln(t_out, blk.norm2, f"h{D}")
             hid = self._mm(h, pre + ".mlp.fc1", blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias, gelu=True,

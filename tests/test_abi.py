@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     assert L.cra5_window_attention_f32(None, None, None, None, 0, 64, 1, 1, 1, 1, 1, 1.0, None) == -7
     assert L.cra5_gemm_nt_split(None, 32, None, 32, None, 0, None, 0, None, None, 0, 1, 1, 32, 1.0, 0, None) == -7
     assert L.cra5_split_f16(None, 0, None, 1, 1, 32, 1.0, None) == -7
-    assert L.cra5_window_attention_split(None, 0, None, None, None, 0, 64, 1, 1, 1, 1, 1, 1.0, None) == -7
+    assert L.cra5_window_attention_split(None, 0, None, None, None, 0, 64, 1, 1, 1, 1, 1, 1.0, 0, None) == -7
     assert L.cra5_pmf_to_quantized_cdf(None, 0, 16, None) == -7
 
 
