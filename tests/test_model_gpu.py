@@ -261,7 +261,7 @@ def test_full268_vs_reference_golden(big, dev, golden_dir):
     assert e_z <= 1e-5 * max(1.0, z_rms)   # z is O(7) with the synthetic gains: relative 1e-5
     # z mod 1 is ~uniform, so a symbol flips with probability 2|err|: expect numel * 2 * 0.8 * rmse
     # flips (4.8 for the reference's own fp32-vs-fp64 error of 1.8e-5); each moves 2 histogram counts.
-    expected_flips = s["z"].numel() * 2 * 0.8 * e_z / max(1.0, z_rms) * max(1.0, z_rms)
+    expected_flips = s["z"].numel() * 2 * 0.8 * e_z
     assert z_hist_l1 <= max(8, 2 * 3 * expected_flips), (z_hist_l1, expected_flips)
     if z_hist_l1 == 0 and z_flips == 0:
         assert e_m <= 1e-5 and e_s <= 1e-5
