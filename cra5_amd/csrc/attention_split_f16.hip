@@ -55,9 +55,10 @@ __device__ __forceinline__ int token_of(const WinGeom &g, int wr, int wc, int t)
 constexpr int HD = 64;
 constexpr int KS = 72;   // K LDS row stride (halves): 144 B
 constexpr int VS = 36;   // V^T LDS row stride (halves): 72 B
+constexpr int MAX_WIN_TOKENS = 1536;   // windowed (not whole-grid) launches: L <= this (12 KB offset table)
 
-template <int NW, bool HI>
-__global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
+template <int NW, bool HI, bool GLOBAL>
+__global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_split_kernel(
     const unsigned short *__restrict__ qkv, long ldq /* halves per row = 2*Kp */,
     const unsigned short *__restrict__ pad_row, float *__restrict__ out, unsigned short *__restrict__ out_s,
     int Kp_out, int C, int heads, WinGeom g, int q_tiles, float scale) {
@@ -68,24 +69,22 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
   // [K hi][K lo] : 32 x KS ;  [V^T hi][V^T lo] : 64 x VS
   constexpr int KPL = 32 * KS + 32;   // K plane stride (halves): +64 B so hi/lo planes hit different bank halves
   constexpr int VPL = 64 * VS + 8;    // V^T plane stride: +16 B
-#ifdef ATT_UNCOND
-#define ATT_IDX(x) min((x), PIECES - 1)
-#define ATT_IF(c)
-#else
-#define ATT_IDX(x) (x)
-#define ATT_IF(c) if (c)
-#endif
-#ifdef ATT_SB
-#define ATT_SCHED() __builtin_amdgcn_sched_barrier(0)
-#else
-#define ATT_SCHED()
-#endif
 #ifndef ATT_LDS_PAD
 #define ATT_LDS_PAD 0
 #endif
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * KPL + 2 * VPL + ATT_LDS_PAD];
+#ifndef ATT_VALU_PER_MFMA
+#define ATT_VALU_PER_MFMA 12
+#endif
+  // two K buffers and two V^T buffers: tile j+1's scores are issued to the matrix pipe BEFORE
+  // the softmax of tile j, so K runs one tile ahead of V; one barrier per key tile.
+  constexpr int KBUF = 2 * KPL, VBUF = 2 * VPL;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * KBUF + 2 * VBUF + ATT_LDS_PAD];
   unsigned short *Ks = lds;
-  unsigned short *Vt = lds + 2 * KPL;
+  unsigned short *Vt = lds + 2 * KBUF;
+  // windowed launches: byte offset (from qkv) of every window token's row, pad tokens -> the pad
+  // row; built once per block so that the per-tile staging needs no division / multiply.
+  constexpr int TAB = GLOBAL ? 1 : MAX_WIN_TOKENS;
+  __shared__ long long tab[TAB];
 
   const int L = g.wh * g.ww;
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
@@ -103,6 +102,13 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
 
   const int tq = (qt * NW + wave) * 32 + l31;
   const int q_tok = (tq < L) ? token_of(g, wr, wc, tq) : -1;
+  if (!GLOBAL) {
+    const long long pad_delta = reinterpret_cast<const char *>(pad_row) - reinterpret_cast<const char *>(qkv);
+    for (int t = tid; t < L; t += NT) {
+      const int tok = token_of(g, wr, wc, t);
+      tab[t] = (tok >= 0) ? (long long)tok * ldq * 2 : pad_delta;
+    }
+  }
   const bool wave_active = __any(q_tok >= 0);
   if (!__syncthreads_or(wave_active ? 1 : 0)) return;
 
@@ -126,142 +132,235 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  uint4 sk[STG], sv[STG];
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-#define CRA5_KV_LOAD(J)                                                                   \
+  const int n_tiles = L / 32;
+  uint4 sk0, sk1 = make_uint4(0u, 0u, 0u, 0u), sv0, sv1 = make_uint4(0u, 0u, 0u, 0u);
+  // K: 16 lanes cover one 256-byte row (coalesced).  V: 32 lanes cover 32 keys at the same
+  // 16-byte column, so that the transposed b16 LDS writes of a half-wave land in 32 consecutive
+  // halves of ONE V^T row (bank-conflict-free).
+  static_assert(STG == 1 || STG == 2, "staging below is written out for one or two 16-byte pieces per thread");
+  constexpr bool TWO = STG == 2;
+  // thread -> (row, piece) of its two K pieces and (row, two pieces) of V; indexes past the tile
+  // (NW = 6: 384 threads x 2 > 512 pieces) are clamped: loaded redundantly, never stored.
+  const int krow0 = tid >> 4, krow1 = min((tid + NT) >> 4, 31);
+  const int vrow = tid & 31;
+  const long kcol = koff + (tid & 15) * 8;                                  // halves
+  const long vcol0 = voff + (tid >> 5) * 8, vcol1 = voff + min((tid + NT) >> 5, 15) * 8;
+  // whole-grid launches walk three running row pointers (+32 rows per tile); windowed ones look
+  // the rows up in the table.
+  const unsigned short *kq0 = qkv + (size_t)krow0 * ldq + kcol;
+  const unsigned short *kq1 = qkv + (size_t)krow1 * ldq + kcol;
+  const unsigned short *vq = qkv + (size_t)vrow * ldq;
+  const long tile_step = 32 * ldq;
+#define CRA5_ROW(JJ, ROW) \
+  reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(qkv) + tab[(JJ)*32 + (ROW)])
+#define CRA5_K_LOAD(J)                                                                    \
   {                                                                                       \
-    _Pragma("unroll") for (int p = 0; p < STG; ++p) {                                     \
-      const int idx = ATT_IDX(tid + p * NT);                                             \
-      sk[p] = zero4;                                                                      \
-      sv[p] = zero4;                                                                      \
-      ATT_IF(idx < PIECES) {                                                              \
-        /* K: 16 lanes cover one 256-byte row (coalesced).  V: 32 lanes cover 32 keys at the  \
-           same 16-byte column, so that the transposed b16 LDS writes of a half-wave land  \
-           in 32 consecutive halves of ONE V^T row (bank-conflict-free). */               \
-        const int row = idx >> 4, piece = idx & 15;                                       \
-        const int vrow = idx & 31, vpiece = idx >> 5;                                     \
-        const int tok = token_of(g, wr, wc, (J)*32 + row);                                \
-        const int vtok = token_of(g, wr, wc, (J)*32 + vrow);                              \
-        const unsigned short *base = (tok >= 0) ? qkv + (size_t)tok * ldq : pad_row;      \
-        const unsigned short *vbase = (vtok >= 0) ? qkv + (size_t)vtok * ldq : pad_row;   \
-        sk[p] = *reinterpret_cast<const uint4 *>(base + koff + piece * 8);                \
-        sv[p] = *reinterpret_cast<const uint4 *>(vbase + voff + vpiece * 8);              \
-      }                                                                                   \
+    if (GLOBAL) {                                                                         \
+      sk0 = *reinterpret_cast<const uint4 *>(kq0);                                        \
+      if (TWO) sk1 = *reinterpret_cast<const uint4 *>(kq1);                               \
+      const long st_ = ((J) < n_tiles - 1) ? tile_step : 0; /* past the end: re-read the last tile */ \
+      kq0 += st_;                                                                         \
+      kq1 += st_;                                                                         \
+    } else {                                                                              \
+      const int jj_ = min((J), n_tiles - 1);                                              \
+      sk0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + kcol);                \
+      if (TWO) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + kcol);       \
+    }                                                                                     \
+  }
+#define CRA5_V_LOAD(J)                                                                    \
+  {                                                                                       \
+    if (GLOBAL) {                                                                         \
+      sv0 = *reinterpret_cast<const uint4 *>(vq + vcol0);                                 \
+      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(vq + vcol1);                        \
+      vq += ((J) < n_tiles - 1) ? tile_step : 0;                                          \
+    } else {                                                                              \
+      const int jj_ = min((J), n_tiles - 1);                                              \
+      const unsigned short *vr_ = CRA5_ROW(jj_, vrow);                                    \
+      sv0 = *reinterpret_cast<const uint4 *>(vr_ + vcol0);                                \
+      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(vr_ + vcol1);                       \
     }                                                                                     \
   }
   // piece -> (chunk = piece>>3, plane = (piece>>2)&1, d0 = 32*chunk + 8*(piece&3))
-#define CRA5_KV_STORE()                                                                   \
+#define CRA5_K_STORE1(P, BUF)                                                             \
   {                                                                                       \
-    _Pragma("unroll") for (int p = 0; p < STG; ++p) {                                     \
-      const int idx = tid + p * NT;                                                       \
-      if (idx < PIECES) {                                                                 \
-        const int row = idx >> 4, piece = idx & 15;                                       \
-        const int plane = (piece >> 2) & 1, d0 = 32 * (piece >> 3) + 8 * (piece & 3);     \
-        *reinterpret_cast<uint4 *>(Ks + plane * KPL + row * KS + d0) = sk[p];             \
-        const int vrow = idx & 31, vpiece = idx >> 5;                                     \
-        const int vplane = (vpiece >> 2) & 1, vd0 = 32 * (vpiece >> 3) + 8 * (vpiece & 3);\
-        unsigned short *vt = Vt + vplane * VPL + vd0 * VS + vrow;                         \
-        const unsigned int w0 = sv[p].x, w1 = sv[p].y, w2 = sv[p].z, w3 = sv[p].w;        \
-        vt[0 * VS] = (unsigned short)(w0 & 0xFFFFu);                                      \
-        vt[1 * VS] = (unsigned short)(w0 >> 16);                                          \
-        vt[2 * VS] = (unsigned short)(w1 & 0xFFFFu);                                      \
-        vt[3 * VS] = (unsigned short)(w1 >> 16);                                          \
-        vt[4 * VS] = (unsigned short)(w2 & 0xFFFFu);                                      \
-        vt[5 * VS] = (unsigned short)(w2 >> 16);                                          \
-        vt[6 * VS] = (unsigned short)(w3 & 0xFFFFu);                                      \
-        vt[7 * VS] = (unsigned short)(w3 >> 16);                                          \
-      }                                                                                   \
+    const int idx = tid + (P)*NT;                                                         \
+    if (idx < PIECES) {                                                                   \
+      const int row = idx >> 4, piece = idx & 15;                                         \
+      const int plane = (piece >> 2) & 1, d0 = 32 * (piece >> 3) + 8 * (piece & 3);       \
+      *reinterpret_cast<uint4 *>(Ks + (BUF)*KBUF + plane * KPL + row * KS + d0) = sk##P;  \
     }                                                                                     \
   }
-
-  const int n_tiles = L / 32;
-  CRA5_KV_LOAD(0);
-  CRA5_KV_STORE();
-  __syncthreads();
-
-  const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + plane*32*KS + 16*s
-  const unsigned short *v_base = Vt + l31 * VS + 4 * h;          // + plane*64*VS + 32*dt*VS + 16*t (+8)
-
-  for (int j = 0; j < n_tiles; ++j) {
-    if (j + 1 < n_tiles) CRA5_KV_LOAD(j + 1);
-    ATT_SCHED();
-
-    if (wave_active) {
-      // ---- S^T tile (32 keys x 32 queries) -----------------------------------------------
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#ifdef ATT_SETPRIO
-      __builtin_amdgcn_s_setprio(2);
+#define CRA5_K_STORE(BUF) { CRA5_K_STORE1(0, BUF) if (TWO) CRA5_K_STORE1(1, BUF) }
+#define CRA5_V_STORE1(P, BUF)                                                             \
+  {                                                                                       \
+    const int idx = tid + (P)*NT;                                                         \
+    if (idx < PIECES) {                                                                   \
+      const int vrow = idx & 31, vpiece = idx >> 5;                                       \
+      const int vplane = (vpiece >> 2) & 1, vd0 = 32 * (vpiece >> 3) + 8 * (vpiece & 3);  \
+      unsigned short *vt = Vt + (BUF)*VBUF + vplane * VPL + vd0 * VS + vrow;              \
+      const unsigned int w0 = sv##P.x, w1 = sv##P.y, w2 = sv##P.z, w3 = sv##P.w;          \
+      vt[0 * VS] = (unsigned short)(w0 & 0xFFFFu);                                        \
+      vt[1 * VS] = (unsigned short)(w0 >> 16);                                            \
+      vt[2 * VS] = (unsigned short)(w1 & 0xFFFFu);                                        \
+      vt[3 * VS] = (unsigned short)(w1 >> 16);                                            \
+      vt[4 * VS] = (unsigned short)(w2 & 0xFFFFu);                                        \
+      vt[5 * VS] = (unsigned short)(w2 >> 16);                                            \
+      vt[6 * VS] = (unsigned short)(w3 & 0xFFFFu);                                        \
+      vt[7 * VS] = (unsigned short)(w3 >> 16);                                            \
+    }                                                                                     \
+  }
+#define CRA5_V_STORE(BUF) { CRA5_V_STORE1(0, BUF) if (TWO) CRA5_V_STORE1(1, BUF) }
+  // S^T tile (32 keys x 32 queries) of the K buffer KB: 12 MFMAs on ATT_S_CHAINS independent
+  // accumulators (a dependent 32x32x16 MFMA cannot issue back-to-back), summed at the end.
+#ifndef ATT_S_CHAINS
+#define ATT_S_CHAINS 1
 #endif
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        const half8 kh = *reinterpret_cast<const half8 *>(k_base + 16 * st);
-        const half8 kl = *reinterpret_cast<const half8 *>(k_base + KPL + 16 * st);
-        if (!HI) {
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], s, 0, 0, 0);
-        }
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
-      }
-      // ---- online softmax, log2 domain ---------------------------------------------------
-      float mloc = s[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * cexp;   // cexp > 0: max commutes with the scale
-      const float m_new = fmaxf(m_run, mloc);
-      float psum = 0.f;
-      half8 ph[2], pl[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], cexp, -m_new));
-        psum += p;
-        const _Float16 hi = (_Float16)p;
-        const _Float16 lo = (_Float16)(p - (float)hi);
-        ph[r >> 3][r & 7] = hi;
-        pl[r >> 3][r & 7] = lo;
-      }
-      if (!__all(m_new == m_run)) {   // exact: skip the rescale when no max moved in this wave
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        m_run = m_new;
-      }
-      l_run += psum;
-      // ---- O^T += V^T . P^T ----------------------------------------------------------------
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        half8 vh[2], vl[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const unsigned short *vp = v_base + 32 * dt * VS + 16 * t;
-          const half4 a0 = *reinterpret_cast<const half4 *>(vp);
-          const half4 a1 = *reinterpret_cast<const half4 *>(vp + 8);
-          const half4 b0 = *reinterpret_cast<const half4 *>(vp + VPL);
-          const half4 b1 = *reinterpret_cast<const half4 *>(vp + VPL + 8);
-          vh[dt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-          vl[dt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        if (!HI) {
-          o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[0], ph[t], o[0], 0, 0, 0);
-          o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[1], ph[t], o[1], 0, 0, 0);
-          o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], pl[t], o[0], 0, 0, 0);
-          o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], pl[t], o[1], 0, 0, 0);
-        }
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], ph[t], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], ph[t], o[1], 0, 0, 0);
-      }
-    }
+#define ATT_KFRAG(PTR, ALT) (*reinterpret_cast<const half8 *>(PTR))
+#define CRA5_SCORES(DST, KB)                                                              \
+  {                                                                                       \
+    f32x16 acc_[ATT_S_CHAINS];                                                            \
+    _Pragma("unroll") for (int c = 0; c < ATT_S_CHAINS; ++c)                              \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[c][r] = 0.f;                    \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                    \
+      const half8 kh = ATT_KFRAG(k_base + (KB)*KBUF + 16 * st, qh[3 - st]);               \
+      const half8 kl = ATT_KFRAG(k_base + (KB)*KBUF + KPL + 16 * st, ql[3 - st]);         \
+      if (!HI) {                                                                          \
+        acc_[(3 * st) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], acc_[(3 * st) % ATT_S_CHAINS], 0, 0, 0); \
+        acc_[(3 * st + 1) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], acc_[(3 * st + 1) % ATT_S_CHAINS], 0, 0, 0); \
+      }                                                                                   \
+      acc_[(3 * st + 2) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], acc_[(3 * st + 2) % ATT_S_CHAINS], 0, 0, 0); \
+    }                                                                                     \
+    _Pragma("unroll") for (int c = 1; c < ATT_S_CHAINS; ++c)                              \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[0][r] += acc_[c][r];            \
+    DST = acc_[0];                                                                        \
+  }
 
-    ATT_SCHED();
-    __syncthreads();
-    if (j + 1 < n_tiles) {
-      CRA5_KV_STORE();
-      __syncthreads();
+  const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
+  const unsigned short *v_base = Vt + l31 * VS + 4 * h;          // + buf*VBUF + plane*VPL + 32*dt*VS + 16*t (+8)
+
+  // cross-half max: lanes l and l+32 own the two halves of one query's 32 scores
+#define CRA5_XHALF_MAX(X)                                                                 \
+  ({                                                                                      \
+    float a_ = (X), b_ = (X);                                                             \
+    asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a_), "+v"(b_));              \
+    fmaxf(a_, b_);                                                                        \
+  })
+#define CRA5_TILE_MAX(S)                                                                  \
+  ({                                                                                      \
+    float m_ = fmaxf(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])), fmaxf(fmaxf(S[4], S[5]), fmaxf(S[6], S[7]))); \
+    float n_ = fmaxf(fmaxf(fmaxf(S[8], S[9]), fmaxf(S[10], S[11])), fmaxf(fmaxf(S[12], S[13]), fmaxf(S[14], S[15]))); \
+    CRA5_XHALF_MAX(fmaxf(m_, n_)) * cexp; /* cexp > 0: max commutes with the scale */      \
+  })
+
+  // prologue: K(0), V(0), K(1) resident; K(2), V(1) in flight; S(0) done
+  CRA5_K_LOAD(0);
+  CRA5_V_LOAD(0);
+  CRA5_K_STORE(0);
+  CRA5_V_STORE(0);
+  CRA5_K_LOAD(1);
+  CRA5_K_STORE(1);
+  __syncthreads();
+  CRA5_K_LOAD(2);
+  CRA5_V_LOAD(1);
+  f32x16 s_cur;
+  CRA5_SCORES(s_cur, 0);
+  float mloc = CRA5_TILE_MAX(s_cur);
+
+  // Waves past the end of the window (q_tok < 0 for all lanes) run the same instruction stream
+  // on the pad row and store nothing: one code path, no divergent barriers.
+  for (int j = 0; j < n_tiles; ++j) {
+    const int kb = (j + 1) & 1, vb = j & 1;
+    // tile j's running max is known before its softmax starts (mloc was reduced in the shadow of
+    // the previous tile's PV MFMAs), so the rare O rescale sits at the top and everything below
+    // is ONE basic block the scheduler can interleave.
+    const float m_new = fmaxf(m_run, mloc);
+    if (!__all(m_new == m_run)) {   // exact: skip the rescale when no max moved in this wave
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_run = m_new;
     }
+    // ---- tile j+1's 12 score MFMAs, interleaved with tile j's softmax VALU work
+    // (past the last tile the scores of a stale K buffer are computed and discarded.)
+    f32x16 s_next;
+#ifdef ATT_SKIP_S
+    s_next = s_cur;
+#else
+    CRA5_SCORES(s_next, kb);
+#endif
+    float psum = 0.f;
+    half8 ph[2], pl[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#if defined(ATT_SKIP_SOFTMAX)
+      const float p = s_cur[r];
+      ph[r >> 3][r & 7] = __builtin_bit_cast(_Float16, (unsigned short)__builtin_bit_cast(unsigned, p));
+      pl[r >> 3][r & 7] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned, p) >> 16));
+      psum += p;
+#else
+      const float p = __builtin_amdgcn_exp2f(fmaf(s_cur[r], cexp, -m_new));
+      psum += p;
+      const _Float16 hi = (_Float16)p;
+      const _Float16 lo = (_Float16)(p - (float)hi);
+      ph[r >> 3][r & 7] = hi;
+      pl[r >> 3][r & 7] = lo;
+#endif
+    }
+    l_run += psum;
+    // ---- O^T += V^T . P^T, with the staging traffic and tile j+1's max in its shadow
+#ifdef ATT_SKIP_PV
+    o[0][0] += (float)ph[0][0] + (float)pl[1][7] + (float)ph[1][3] + (float)pl[0][5];
+#else
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      half8 vh[2], vl[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const unsigned short *vp = v_base + vb * VBUF + 32 * dt * VS + 16 * t;
+        const half4 a0 = *reinterpret_cast<const half4 *>(vp);
+        const half4 a1 = *reinterpret_cast<const half4 *>(vp + 8);
+        const half4 b0 = *reinterpret_cast<const half4 *>(vp + VPL);
+        const half4 b1 = *reinterpret_cast<const half4 *>(vp + VPL + 8);
+        vh[dt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        vl[dt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      if (!HI) {
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[0], ph[t], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[1], ph[t], o[1], 0, 0, 0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], pl[t], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], pl[t], o[1], 0, 0, 0);
+      }
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], ph[t], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], ph[t], o[1], 0, 0, 0);
+    }
+#endif
+    s_cur = s_next;
+    mloc = CRA5_TILE_MAX(s_cur);
+#ifdef ATT_SGB
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 K-fragment ds_reads first
+#pragma unroll
+    for (int i = 0; i < (HI ? 4 : 12); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one score MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, ATT_VALU_PER_MFMA, 0);  // softmax VALU in its shadow
+    }
+#endif
+    // K(j+2) -> the buffer tile j's scores came from (last read before the previous barrier),
+    // V(j+1) -> the other V buffer (past the end: stale data into buffers nobody reads);
+    // then start fetching K(j+3), V(j+2).
+#ifndef ATT_SKIP_STAGE
+    CRA5_K_STORE(j & 1);
+#ifndef ATT_SKIP_VSTORE
+    CRA5_V_STORE((j + 1) & 1);
+#endif
+    CRA5_K_LOAD(j + 3);
+    CRA5_V_LOAD(j + 2);
+#endif
+#ifndef ATT_SKIP_BARRIER
+    __syncthreads();
+#endif
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -285,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, 2) void window_attention_split_kernel(
   }
 }
 
-template <int NW, bool HI>
+template <int NW, bool HI, bool GLOBAL>
 int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, float *out, unsigned short *out_s,
            int Kp_out, int C, int heads, int H, int W, int wh, int ww, float scale, hipStream_t st) {
   WinGeom g;
@@ -297,7 +396,7 @@ int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, f
   g.nwc = (W + ww - 1) / ww;
   const int L = wh * ww;
   const int q_tiles = (L + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL((window_attention_split_kernel<NW, HI>), dim3(q_tiles * nwr * g.nwc * heads), dim3(NW * 64), 0, st,
+  hipLaunchKernelGGL((window_attention_split_kernel<NW, HI, GLOBAL>), dim3(q_tiles * nwr * g.nwc * heads), dim3(NW * 64), 0, st,
                      qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, q_tiles, scale);
   return (int)hipGetLastError();
 }
@@ -315,15 +414,22 @@ extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp
   hipStream_t st = (hipStream_t)stream;
   const int L = wh * ww;
   const long ldq = 2L * qkv_kp;
-  if (hi_only) {
-    if (L % 192 == 0 && L <= 1152)
-      return launch<6, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
-    return launch<4, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
-  }
-  if (L % 192 == 0 && L <= 1152)
-    return launch<6, false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+  const bool whole = (wh == H && ww == W);
+  if (!whole && L > MAX_WIN_TOKENS) return CRA5_ERR_ARG;   // attention_f32.hip covers those
+#define CRA5_ATT_GO(NWV, HIV, GLV) \
+  return launch<NWV, HIV, GLV>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st)
 #ifndef ATT_NW_GLOBAL
-#define ATT_NW_GLOBAL 4
+#define ATT_NW_GLOBAL 8   /* 256 queries share each K/V tile: half the staging of 4 waves (1.63 vs 1.71 ms) */
 #endif
-  return launch<ATT_NW_GLOBAL, false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+  if (whole) {
+    if (hi_only) CRA5_ATT_GO(ATT_NW_GLOBAL, true, true);
+    CRA5_ATT_GO(ATT_NW_GLOBAL, false, true);
+  }
+  if (L % 192 == 0 && L <= 1152) {
+    if (hi_only) CRA5_ATT_GO(6, true, false);
+    CRA5_ATT_GO(6, false, false);
+  }
+  if (hi_only) CRA5_ATT_GO(4, true, false);
+  CRA5_ATT_GO(4, false, false);
+#undef CRA5_ATT_GO
 }

@@ -100,6 +100,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE];
 
   CRA5_TRACE(0);
+#ifdef CRA5_GEMM_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 5 + 4] = clock64();
+#endif
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = pid / tiles_n, tn = pid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -343,6 +346,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
     }
   }
   CRA5_TRACE(3);
+#ifdef CRA5_GEMM_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 5 + 4] = clock64() - g_gemm_trace[blockIdx.x * 5 + 4];
+#endif
 }
 
 // fp32 [rows][K] (row stride ldx) -> split-f16 [rows][2*Kp] halves, x * scale, pad zeros.

@@ -2,6 +2,7 @@
 function passes raw `data_ptr()`s + sizes + the current HIP stream to the native
 library.  Device entry points refuse non-GPU tensors (no CPU fallback)."""
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -21,9 +22,14 @@ class KernelTimer:
     every launch of one kernel family, so sum(work) / sum(duration) is that kernel's
     achieved rate over the timed region."""
 
-    def __init__(self):
+    def __init__(self, sample_every=1):
+        """sample_every = n: bracket every n-th launch only (per calling thread).  Event records
+        are queue packets between the kernels; at ~400 timed launches per frame they cost ~5 %
+        of the frame rate, sampling keeps the timed region honest."""
         self.records = {}   # kind -> list of (start_ev, stop_ev, work)
         self._free = []
+        self.sample_every = max(1, int(sample_every))
+        self._tls = threading.local()
 
     def _ev(self):
         if self._free:
@@ -33,11 +39,18 @@ class KernelTimer:
         return e
 
     def start(self):
+        if self.sample_every > 1:
+            n = getattr(self._tls, "n", 0) + 1
+            self._tls.n = n
+            if n % self.sample_every:
+                return None
         e = self._ev()
         check(lib().cra5_event_record(e, _stream()), "cra5_event_record")
         return e
 
     def stop(self, kind, start_ev, work):
+        if start_ev is None:
+            return
         e = self._ev()
         check(lib().cra5_event_record(e, _stream()), "cra5_event_record")
         self.records.setdefault(kind, []).append((start_ev, e, work))
@@ -235,8 +248,15 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
     return out if out is not None else out_split
 
 
-def split_attention_ok(C, heads, wh, ww):
-    return C % heads == 0 and C // heads == 64 and (wh * ww) % 32 == 0
+MAX_WIN_TOKENS = 1536   # csrc/attention_split_f16.hip: windowed launches keep a per-block row-offset table
+
+
+def split_attention_ok(C, heads, wh, ww, H=None, W=None):
+    """Shapes the f16-MFMA attention kernel takes: head dim 64, window length a multiple of 32,
+    and either the whole (H, W) grid as one window or a window of <= MAX_WIN_TOKENS tokens."""
+    L = wh * ww
+    return (C % heads == 0 and C // heads == 64 and L % 32 == 0
+            and (L <= MAX_WIN_TOKENS or (wh == H and ww == W)))
 
 
 def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split=None):

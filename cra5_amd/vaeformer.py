@@ -21,6 +21,7 @@ import contextlib
 import math
 import os
 import threading
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -268,6 +269,9 @@ class VAEformer(nn.Module):
         # g_a / g_s projections and attention use plain f16 operands (1 MFMA per product, fp32
         # accumulate); the hyper-prior / GaussianConditional side stays fp32-accurate so that
         # encoder and decoder derive identical CDF indexes.  RMSE-gated in tests/test_model_gpu.py.
+        # optional timeline of the GPU phases: a list receives (thread id, t_request, t_start, t_end)
+        # per phase (tools/phase_timeline.py); None = off
+        self.phase_log = None
         self.precision = os.environ.get("CRA5_PRECISION", "fp32")
         if self.precision not in ("fp32", "f16"):
             raise ValueError("CRA5_PRECISION must be 'fp32' or 'f16'")
@@ -431,7 +435,7 @@ class VAEformer(nn.Module):
         split = self.gemm_mode == "split"
         h = self._ln(t_in, blk.norm1, f"h{D}")
         wh, ww = blk.window if blk.window is not None else (H, W)
-        if split and self.attn_mode == "split" and ops.split_attention_ok(D, blk.heads, wh, ww):
+        if split and self.attn_mode == "split" and ops.split_attention_ok(D, blk.heads, wh, ww, H, W):
             # qkv never exists in fp32: GEMM epilogue -> split-f16 -> f16-MFMA attention -> split
             qkv_s = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out_name=f"qkv{D}")
             pad_s = self._derive("pad." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)))
@@ -587,13 +591,20 @@ class VAEformer(nn.Module):
         flight (cra5_amd/pipeline.py) phases of different frames take turns on the GPU at this
         granularity while the other frames sit in their host rANS phase: every kernel runs
         alone on the chip (clean per-kernel timing, no L2 thrash between frames)."""
+        log = self.phase_log
+        t0 = time.perf_counter() if log is not None else 0.0
         if not self.gpu_exclusive:
             yield
             torch.cuda.current_stream().synchronize()
+            if log is not None:
+                log.append((threading.get_ident(), t0, t0, time.perf_counter()))
             return
         with self._gpu_lock:
+            t1 = time.perf_counter() if log is not None else 0.0
             yield
             torch.cuda.current_stream().synchronize()
+            if log is not None:
+                log.append((threading.get_ident(), t0, t1, time.perf_counter()))
 
     def _scale_bound(self):
         """GaussianConditional.lower_bound_scale.bound as a host float, cached: reading a device

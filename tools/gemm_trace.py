@@ -55,6 +55,9 @@ for name, M, N, K, gelu, res, so in SHAPES:
     starts = us[order, 0]
     print(f"      block start times: p0 {starts[0]:.1f} p25 {np.percentile(starts,25):.1f} p50 {np.percentile(starts,50):.1f} "
           f"p75 {np.percentile(starts,75):.1f} p100 {starts[-1]:.1f};  end p50 {np.percentile(us[:,3],50):.1f} p100 {span:.1f}")
+    cyc = buf[:, 4].astype(np.int64)[used]
+    ghz = cyc / ((t[:, 3] - t[:, 0]) * 10.0)     # shader cycles per ns
+    print(f"      shader clock while the block ran: mean {ghz.mean():.2f} GHz (min {ghz.min():.2f}, max {ghz.max():.2f})")
     flop = 2.0 * M * N * K
     print(f"      rate: whole {flop/span/1e6:6.1f} TF, main-loop-only per block {flop/n/ (main.mean())/1e6*256:6.1f} TF-equivalent at 256 CUs")
     del a, w, sa, sw, out, r, sm
