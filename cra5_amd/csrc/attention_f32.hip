@@ -31,6 +31,7 @@
 //     skip the MFMA work but keep staging tiles.
 //   * block ids are XCD-remapped so the blocks of one (window, head) share an L2.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <math.h>
 
 #include "../../include/cra5_amd.h"
@@ -290,6 +291,19 @@ extern "C" int cra5_window_attention_f32(const float *qkv, const float *pad_row,
     if (L % 192 == 0 && L <= 1152) return launch<64, 6>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
     return launch<64, 4>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
   }
-  if (hd == 72) return launch<72, 4>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
+  if (hd == 72) {
+    // hyper-prior (648 tokens, 5 heads): 128-query blocks would be 30 blocks on 256 CUs;
+    // one wave (32 queries) per block -> 105 blocks.  CRA5_ATT72_NW overrides (1 | 2 | 4).
+    static const int forced = [] {
+      const char *e = getenv("CRA5_ATT72_NW");
+      return e ? atoi(e) : 0;
+    }();
+    const int nwr = (H + wh - 1) / wh, nwc = (W + ww - 1) / ww;
+    const long blocks4 = (long)((L + 127) / 128) * nwr * nwc * heads;
+    const int nw = forced ? forced : (blocks4 < 128 ? 1 : 4);
+    if (nw == 1) return launch<72, 1>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
+    if (nw == 2) return launch<72, 2>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
+    return launch<72, 4>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
+  }
   return CRA5_ERR_ARG;
 }

@@ -112,43 +112,45 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  // staging map: thread -> (row, plane, logical piece).  The lo plane of row r^1 rides with
-  // the hi plane of row r so that the 8 lanes of a ds_write_b128 group hit both bank halves.
-  const int c8 = tid & 7;
-  const int plane = c8 >> 2, pc = c8 & 3;
-  const int r0 = (tid >> 3) ^ plane;
-  const int wr_off = plane * ROW_H / 2 * 0;  // (planes are separate arrays; kept for clarity)
-  (void)wr_off;
-
-  uint4 ra[A_P], rb[B_P];
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-
-#define CRA5_GLOAD(KT)                                                                         \
-  {                                                                                            \
-    _Pragma("unroll") for (int p = 0; p < A_P; ++p) {                                          \
-      const int r_ = m0 + r0 + p * ROWS_PER_PASS;                                              \
-      ra[p] = zero4;                                                                           \
-      if (r_ < M)                                                                              \
-        ra[p] = *reinterpret_cast<const uint4 *>(A + (size_t)r_ * lda + (size_t)(KT)*64 + plane * 32 + pc * 8); \
-    }                                                                                          \
-    _Pragma("unroll") for (int p = 0; p < B_P; ++p) {                                          \
-      const int r_ = n0 + r0 + p * ROWS_PER_PASS;                                              \
-      rb[p] = zero4;                                                                           \
-      if (r_ < N)                                                                              \
-        rb[p] = *reinterpret_cast<const uint4 *>(W + (size_t)r_ * ldw + (size_t)(KT)*64 + plane * 32 + pc * 8); \
-    }                                                                                          \
+  // Staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 16 rows x 64 B of one
+  // plane straight into LDS - no staging VGPRs, no ds_write pass (ds_write_b128 runs at ~79 B/clk,
+  // it was ~830 exposed cycles per k-step).  The destination is wave-uniform base + lane*16, i.e.
+  // LINEAR: row = lane/4, physical piece = lane%4; the XOR swizzle is therefore applied to the
+  // per-lane SOURCE address: lane fetches logical piece (lane%4) ^ ((row>>2)&3) = (lane&3)^(lane>>4).
+  // A stage is [A hi][A lo][W hi][W lo] = (2BM + 2BN)/16 one-KB groups, dealt round-robin to
+  // the waves.  Rows past M / N are clamped to the last row (duplicates, never stored).
+  constexpr int GROUPS = (2 * BM + 2 * BN) / 16;
+  constexpr int NWAVE = WM * WN;
+  static_assert(GROUPS % NWAVE == 0, "groups must divide evenly over the waves");
+  constexpr int IPW = GROUPS / NWAVE;      // LDS-DMA instructions per wave per k-step
+  const unsigned short *src[IPW];
+  {
+    const int lrow = lane >> 2, lpiece = (lane & 3) ^ (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) {
+      const int gid = wave + q * NWAVE;          // group id inside the stage
+      const int grow = gid * 16;                 // first row of the group in [A hi | A lo | W hi | W lo]
+      const bool isA = grow < 2 * BM;
+      const int rr = isA ? grow : grow - 2 * BM;
+      const int plane_ = isA ? (rr >= BM) : (rr >= BN);
+      const int row_ = (isA ? rr - plane_ * BM : rr - plane_ * BN) + lrow;
+      if (isA)
+        src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + plane_ * 32 + lpiece * 8;
+      else
+        src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + plane_ * 32 + lpiece * 8;
+    }
   }
-#define CRA5_SSTORE(BUF)                                                                       \
+  // (the builtin only exists in the device pass; the host pass just needs the launch stub)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRA5_GLDS16(SRC, DST) __builtin_amdgcn_global_load_lds(SRC, DST, 16, 0, 0)
+#else
+#define CRA5_GLDS16(SRC, DST) (void)(SRC)
+#endif
+#define CRA5_STAGE_LOAD(BUF)                                                                   \
   {                                                                                            \
-    unsigned short *as_ = lds + (BUF)*STAGE + plane * BM * ROW_H;                              \
-    unsigned short *bs_ = lds + (BUF)*STAGE + 2 * BM * ROW_H + plane * BN * ROW_H;             \
-    _Pragma("unroll") for (int p = 0; p < A_P; ++p) {                                          \
-      const int r_ = r0 + p * ROWS_PER_PASS;                                                   \
-      *reinterpret_cast<uint4 *>(as_ + r_ * ROW_H + ((pc ^ ((r_ >> 2) & 3)) << 3)) = ra[p];    \
-    }                                                                                          \
-    _Pragma("unroll") for (int p = 0; p < B_P; ++p) {                                          \
-      const int r_ = r0 + p * ROWS_PER_PASS;                                                   \
-      *reinterpret_cast<uint4 *>(bs_ + r_ * ROW_H + ((pc ^ ((r_ >> 2) & 3)) << 3)) = rb[p];    \
+    _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                          \
+      CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave + q * NWAVE) * 512);                       \
+      src[q] += 64;  /* next k-step: 128 B further along the row */                            \
     }                                                                                          \
   }
 
@@ -172,58 +174,66 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   poff[0] = ((0 + h) ^ sw) << 3;
   poff[1] = ((2 + h) ^ sw) << 3;
 
+  // fragments of one 16-wide k-half (KK = 0 | 1) of stage ST
+#define CRA5_FRAG_READ(AH, AL, BH, BL, ST, KK)                                                 \
+  {                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                           \
+      AH[i] = *reinterpret_cast<const half8 *>((ST) + a_row + i * 32 * ROW_H + poff[KK]);      \
+      if (NPROD == 3) AL[i] = *reinterpret_cast<const half8 *>((ST) + a_row + BM * ROW_H + i * 32 * ROW_H + poff[KK]); \
+    }                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
+      BH[j] = *reinterpret_cast<const half8 *>((ST) + b_row + j * 32 * ROW_H + poff[KK]);      \
+      if (NPROD == 3) BL[j] = *reinterpret_cast<const half8 *>((ST) + b_row + BN * ROW_H + j * 32 * ROW_H + poff[KK]); \
+    }                                                                                          \
+  }
+  // small terms first, plane-major: TM*TN independent accumulators between dependent MFMAs.
+  // NPROD == 1 is the reduced-precision mode (BASELINE.json configs[4]): hi.hi only = plain f16.
+#define CRA5_MFMA_GROUP(AH, AL, BH, BL)                                                        \
+  {                                                                                            \
+    if (NPROD == 3) {                                                                          \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0); \
+    }                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);  \
+  }
+
+  // Main loop, ONE barrier per k-step, placed between the two 16-wide halves so that nothing
+  // waits right after it:
+  //     read F1 = second-half fragments of tile kt | MFMA(F0)
+  //     barrier   (own LDS-DMA of tile kt+1 drained first: it was issued a full step ago)
+  //     read F0 = first-half fragments of tile kt+1, start the LDS-DMA of tile kt+2 into the
+  //     stage tile kt just vacated | MFMA(F1)
+  // Measured (tools/gemm_trace.py variants): with the barrier at the end of the step the matrix
+  // pipe idled through barrier skew + the first ds_reads of the new stage, 20 of 78 us per tile.
   const int nk = Kp / BK;
-  CRA5_GLOAD(0);
-  CRA5_SSTORE(0);
-  if (STAGES == 2 && nk > 1) CRA5_GLOAD(1);
-  __syncthreads();
+  half8 f0ah[TM], f0al[TM], f0bh[TN], f0bl[TN], f1ah[TM], f1al[TM], f1bh[TN], f1bl[TN];
+  CRA5_STAGE_LOAD(0);
+  __syncthreads();   // (hipcc drains vmcnt before the barrier: tile 0 has landed for everyone)
+  CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds, 0);
+  if (nk > 1) CRA5_STAGE_LOAD(1);
   CRA5_TRACE(1);
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = (STAGES == 2) ? (kt & 1) : 0;
-    if (STAGES == 2) {
-      // tile kt+1 (in registers since the previous step) -> the other stage, then prefetch kt+2
-      if (kt + 1 < nk) CRA5_SSTORE(cur ^ 1);
-      if (kt + 2 < nk) CRA5_GLOAD(kt + 2);
-    } else {
-      // single stage (two co-resident blocks per CU cover each other's barriers / epilogues):
-      // fetch tile kt+1 into registers while tile kt is consumed
-      if (kt + 1 < nk) CRA5_GLOAD(kt + 1);
-    }
+    const int cur = kt & 1;
     const unsigned short *st = lds + cur * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      half8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const half8 *>(st + a_row + i * 32 * ROW_H + poff[kk]);
-        if (NPROD == 3) al[i] = *reinterpret_cast<const half8 *>(st + a_row + BM * ROW_H + i * 32 * ROW_H + poff[kk]);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const half8 *>(st + b_row + j * 32 * ROW_H + poff[kk]);
-        if (NPROD == 3) bl[j] = *reinterpret_cast<const half8 *>(st + b_row + BN * ROW_H + j * 32 * ROW_H + poff[kk]);
-      }
-      // small terms first, plane-major: TM*TN independent accumulators between dependent MFMAs.
-      // NPROD == 1 is the reduced-precision mode (BASELINE.json configs[4]): hi.hi only = plain f16.
-      if (NPROD == 3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    CRA5_FRAG_READ(f1ah, f1al, f1bh, f1bl, st, 1);
+    CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
+#ifndef GEMM_SKIP_BARRIER   /* GEMM_SKIP_* : timing experiments of tools/gemm_trace.py (wrong results) */
+    __syncthreads();   // tile kt+1 visible to everyone; everyone is done reading tile kt's stage
+#endif
+    if (kt + 1 < nk) {
+      CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds + (cur ^ 1) * STAGE, 0);
+#ifndef GEMM_SKIP_STAGE
+      if (kt + 2 < nk) CRA5_STAGE_LOAD(cur);
+#endif
     }
+    CRA5_MFMA_GROUP(f1ah, f1al, f1bh, f1bl);
     if (LONGK && ((kt & 15) == 15)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -235,12 +245,8 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
             acc[i][j][r] = 0.f;
           }
     }
-    __syncthreads();   // stage cur fully consumed (STAGES == 2: and stage cur^1 fully written)
-    if (STAGES == 1 && kt + 1 < nk) {
-      CRA5_SSTORE(0);
-      __syncthreads();
-    }
   }
+  __syncthreads();   // the epilogue reuses the stages as scratch
 
   CRA5_TRACE(2);
   const bool has_bias = flags & CRA5_EPI_BIAS;
