@@ -199,7 +199,7 @@ def main():
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             nprod = 3.0 if net.precision == "fp32" else 1.0
             peak = PEAK_F16_MFMA_TFLOPS / nprod
-            out["roofline"] = {"kernel": "gemm_nt_split_kernel", "bound": "mfma", "achieved": ach, "peak": peak,
+            out["roofline"] = {"kernel": "gemm_nt_split_kernel<2,4,{3|4},2> (192x256 / 256x256 tiles)", "bound": "mfma", "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": measured_traffic(),
                                "traffic_note": "bytes/launch at the L2<->fabric boundary (Infinity-Cache hits "
                                                "included), profiles/r01_traffic.json; algorithmic minimum "
@@ -208,6 +208,12 @@ def main():
                                "mfma_tflops_issued": nprod * ach, "launches": g["launches"],
                                "avg_launch_ms": g["ms"] / g["launches"], "gemm_ms_per_step": g["ms"] * sample / steps,
                                "launches_sampled_every": sample}
+        gs = summ.get("gemm_nt_split_small")
+        if gs and gs["ms"] > 0 and "roofline" in out:
+            out["roofline"]["small_tile_launches"] = {
+                "kernel": "gemm_nt_split_kernel<2,2,1,1> (64x64 tiles: hyper-prior / head GEMMs, launch-bound)",
+                "launches": gs["launches"], "ms_per_step": gs["ms"] * sample / steps,
+                "achieved": gs["work"] / (gs["ms"] * 1e-3) / 1e12}
         g = summ.get("gemm_nt_f32")
         if g and g["ms"] > 0 and "roofline" not in out:
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12

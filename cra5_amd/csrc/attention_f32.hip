@@ -292,15 +292,18 @@ extern "C" int cra5_window_attention_f32(const float *qkv, const float *pad_row,
     return launch<64, 4>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
   }
   if (hd == 72) {
-    // hyper-prior (648 tokens, 5 heads): 128-query blocks would be 30 blocks on 256 CUs;
-    // one wave (32 queries) per block -> 105 blocks.  CRA5_ATT72_NW overrides (1 | 2 | 4).
+    // hyper-prior (648 tokens, 5 heads): 30 blocks of 4 waves.  Fewer waves per block = more blocks
+    // but every block still walks all 21 key tiles, each a serial chain of exact-f32 MFMAs:
+    // measured 83 / 88 / 102 us for 4 / 2 / 1 waves (tools/attn_bench.py) - the fix is splitting
+    // the KEYS over waves, not the queries.  CRA5_ATT72_NW overrides (1 | 2 | 4).
     static const int forced = [] {
       const char *e = getenv("CRA5_ATT72_NW");
       return e ? atoi(e) : 0;
     }();
     const int nwr = (H + wh - 1) / wh, nwc = (W + ww - 1) / ww;
     const long blocks4 = (long)((L + 127) / 128) * nwr * nwc * heads;
-    const int nw = forced ? forced : (blocks4 < 128 ? 1 : 4);
+    (void)blocks4;
+    const int nw = forced ? forced : 4;
     if (nw == 1) return launch<72, 1>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
     if (nw == 2) return launch<72, 2>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);
     return launch<72, 4>(qkv, pad_row, out, out_s, Kp, C, heads, H, W, wh, ww, scale, st);

@@ -185,7 +185,10 @@ def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=Non
                                    _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv), flags,
                                    _stream()), "cra5_gemm_nt_split")
     if ev is not None:
-        TIMER.stop("gemm_nt_split", ev, 2.0 * M * N * a.K)
+        # same rule as gemm_dispatch(): < 256 128x128 tiles -> the 64x64-tile instantiation (hyper-prior
+        # and head GEMMs: microseconds, launch-bound); everything else is the 192/256-row-tile kernel
+        small = ((M + 127) // 128) * ((N + 127) // 128) < 256
+        TIMER.stop("gemm_nt_split_small" if small else "gemm_nt_split", ev, 2.0 * M * N * a.K)
     return out
 
 
