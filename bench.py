@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--exclusive", action="store_true",
                     help="timed region with exclusive GPU phases (one frame's kernels at a time) instead of "
                          "overlapping HIP streams")
+    ap.add_argument("--gpu-slots", type=int, default=int(os.environ.get("CRA5_GPU_SLOTS", "3")),
+                    help="at most this many frames inside a GPU phase at a time (0 = unlimited)")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="frames of the un-overlapped kernel-timing pass run after the timed region")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "8")),
@@ -142,6 +144,7 @@ def main():
     # another's: +15-25 % frames/s), which makes a single launch's start->stop duration
     # depend on what else is running; --exclusive serialises the phases instead.
     net.gpu_exclusive = bool(args.exclusive)
+    net.gpu_slots = args.gpu_slots
     net.precision = args.precision
     torch.cuda.synchronize()
     D.barrier()

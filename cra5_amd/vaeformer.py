@@ -278,6 +278,13 @@ class VAEformer(nn.Module):
         self._derived = {}
         self._derive_lock = threading.RLock()
         self._gpu_lock = threading.Lock()
+        # gpu_slots = n > 0: at most n frames inside a GPU phase at a time (shared-stream mode only):
+        # keeps a kernel's tail filled by another frame's blocks without letting ALL frames fall
+        # into the host (rANS) phase together, which idles the GPU.  0 = unlimited.
+        self.gpu_slots = int(os.environ.get("CRA5_GPU_SLOTS", "3"))
+        self._gpu_sem = None
+        # the ~1 ms h_s phase between the two host phases of a decode does not queue for a slot
+        self.light_bypass = os.environ.get("CRA5_LIGHT_BYPASS", "1") != "0"
         self._tls = threading.local()  # per-thread workspaces: one frame pipeline per thread/stream
         self.eval()
 
@@ -585,7 +592,7 @@ class VAEformer(nn.Module):
 
     # ---- GPU phases -------------------------------------------------------------------------
     @contextlib.contextmanager
-    def _gpu_phase(self):
+    def _gpu_phase(self, light=False):
         """One frame's GPU phase (a run of kernel launches ended by a stream sync, which the
         device->host hand-off to the entropy coder needs anyway).  When several frames are in
         flight (cra5_amd/pipeline.py) phases of different frames take turns on the GPU at this
@@ -594,10 +601,24 @@ class VAEformer(nn.Module):
         log = self.phase_log
         t0 = time.perf_counter() if log is not None else 0.0
         if not self.gpu_exclusive:
-            yield
-            torch.cuda.current_stream().synchronize()
+            sem = None
+            if self.gpu_slots > 0 and not (light and self.light_bypass):
+                sem = self._gpu_sem
+                if sem is None or sem[0] != self.gpu_slots:
+                    with self._gpu_lock:
+                        sem = self._gpu_sem
+                        if sem is None or sem[0] != self.gpu_slots:
+                            sem = self._gpu_sem = (self.gpu_slots, threading.BoundedSemaphore(self.gpu_slots))
+                sem[1].acquire()
+            t1 = time.perf_counter() if log is not None else 0.0
+            try:
+                yield
+                torch.cuda.current_stream().synchronize()
+            finally:
+                if sem is not None:
+                    sem[1].release()
             if log is not None:
-                log.append((threading.get_ident(), t0, t0, time.perf_counter()))
+                log.append((threading.get_ident(), t0, t1, time.perf_counter()))
             return
         with self._gpu_lock:
             t1 = time.perf_counter() if log is not None else 0.0
@@ -723,7 +744,7 @@ class VAEformer(nn.Module):
         z_idx = eb._build_indexes((1, Cz, zh, zw))
         z_host = self._pinned("z_in", (Cz, zh * zw), torch.int32)
         z_host.copy_(torch.from_numpy(eb.decode_symbols(z_string, z_idx)).view(Cz, zh * zw))
-        with self._gpu_phase():
+        with self._gpu_phase(light=True):
             z_sym = z_host.to(self.device, non_blocking=True)
             med, _ = eb.device_params()
             z_hat = ops.entropy_bottleneck(med, None, sym_in=z_sym, want=("z_hat",))["z_hat"]
