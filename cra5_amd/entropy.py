@@ -105,9 +105,9 @@ class EntropyModel(nn.Module):
         cdf, length, offset = self.host_tables()
         return ops.rans_encode(symbols, indexes, cdf, length, offset)
 
-    def decode_symbols(self, string, indexes):
+    def decode_symbols(self, string, indexes, out=None):
         cdf, length, offset = self.host_tables()
-        return ops.rans_decode(string, indexes, cdf, length, offset)
+        return ops.rans_decode(string, indexes, cdf, length, offset, out=out)
 
 
 def eb_pack_params(sd, prefix="entropy_bottleneck"):

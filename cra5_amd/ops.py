@@ -395,11 +395,15 @@ def rans_encode(symbols, indexes, cdf, cdf_len, offsets):
         lib().cra5_free(out)
 
 
-def rans_decode(data, indexes, cdf, cdf_len, offsets):
-    """-> int32 numpy array of len(indexes)."""
+def rans_decode(data, indexes, cdf, cdf_len, offsets, out=None):
+    """-> int32 numpy array of len(indexes) (written into `out`, a contiguous int32 array of that
+    size, when given: e.g. the numpy view of a pinned staging tensor)."""
     i = _np_i32(indexes).reshape(-1)
     c, l, o = _np_i32(cdf), _np_i32(cdf_len).reshape(-1), _np_i32(offsets).reshape(-1)
-    out = np.empty(i.size, dtype=np.int32)
+    if out is None:
+        out = np.empty(i.size, dtype=np.int32)
+    elif not (isinstance(out, np.ndarray) and out.dtype == np.int32 and out.flags.c_contiguous and out.size == i.size):
+        raise ValueError("`out` must be a contiguous int32 numpy array with one entry per index")
     buf = (ctypes.c_char * len(data)).from_buffer_copy(data)
     check(lib().cra5_rans_decode_with_indexes(ctypes.addressof(buf), len(data), i.ctypes.data, i.size, c.ctypes.data,
                                               c.shape[0], c.shape[1], l.ctypes.data, o.ctypes.data, out.ctypes.data),

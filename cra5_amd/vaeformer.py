@@ -743,7 +743,7 @@ class VAEformer(nn.Module):
         zh, zw = int(shape[0]), int(shape[1])
         z_idx = eb._build_indexes((1, Cz, zh, zw))
         z_host = self._pinned("z_in", (Cz, zh * zw), torch.int32)
-        z_host.copy_(torch.from_numpy(eb.decode_symbols(z_string, z_idx)).view(Cz, zh * zw))
+        eb.decode_symbols(z_string, z_idx, out=z_host.numpy().reshape(-1))   # straight into pinned memory
         with self._gpu_phase(light=True):
             z_sym = z_host.to(self.device, non_blocking=True)
             med, _ = eb.device_params()
@@ -755,7 +755,7 @@ class VAEformer(nn.Module):
                                            scale_bound=self._scale_bound())["idx"]
             idx_h = self._to_host("idx", idx)
         y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
-        y_host.copy_(torch.from_numpy(gc.decode_symbols(y_string, idx_h.numpy().reshape(-1))).view(means.shape))
+        gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
         with self._gpu_phase():
             y_sym = y_host.to(self.device, non_blocking=True)
             y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym, want=("y_hat",))["y_hat"]
