@@ -31,6 +31,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+// hardware transpose read (gfx950): 64 bits per lane, 16-bit elements exchanged inside 16-lane groups
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRA5_TR_READ(P) \
+  __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4 *)(P)))
+#else
+#define CRA5_TR_READ(P) (*reinterpret_cast<const half4 *>(P))
+#endif
 
 namespace {
 
@@ -54,7 +62,7 @@ __device__ __forceinline__ int token_of(const WinGeom &g, int wr, int wc, int t)
 
 constexpr int HD = 64;
 constexpr int KS = 72;   // K LDS row stride (halves): 144 B
-constexpr int VS = 36;   // V^T LDS row stride (halves): 72 B
+constexpr int VS = 96;   // V LDS row stride (halves): 192 B - see the ds_read_b64_tr_b16 note in the kernel
 constexpr int MAX_WIN_TOKENS = 1536;   // windowed (not whole-grid) launches: L <= this (12 KB offset table)
 
 template <int NW, bool HI, bool GLOBAL>
@@ -66,9 +74,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   constexpr int PIECES = 32 * 16;                 // 16-byte pieces per K (or V) tile
   constexpr int STG = (PIECES + NT - 1) / NT;
 
-  // [K hi][K lo] : 32 x KS ;  [V^T hi][V^T lo] : 64 x VS
+  // [K hi][K lo] : 32 x KS ;  [V hi][V lo] : 32 x VS (row-major like K, transposed by the READ)
   constexpr int KPL = 32 * KS + 32;   // K plane stride (halves): +64 B so hi/lo planes hit different bank halves
-  constexpr int VPL = 64 * VS + 8;    // V^T plane stride: +16 B
+  constexpr int VPL = 32 * VS;        // V plane stride
 #ifndef ATT_LDS_PAD
 #define ATT_LDS_PAD 0
 #endif
@@ -141,15 +149,15 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   constexpr bool TWO = STG == 2;
   // thread -> (row, piece) of its two K pieces and (row, two pieces) of V; indexes past the tile
   // (NW = 6: 384 threads x 2 > 512 pieces) are clamped: loaded redundantly, never stored.
-  const int krow0 = tid >> 4, krow1 = min((tid + NT) >> 4, 31);
-  const int vrow = tid & 31;
+  const int krow0 = min(tid >> 4, 31), krow1 = min((tid + NT) >> 4, 31);
   const long kcol = koff + (tid & 15) * 8;                                  // halves
-  const long vcol0 = voff + (tid >> 5) * 8, vcol1 = voff + min((tid + NT) >> 5, 15) * 8;
+  const long vcol = voff + (tid & 15) * 8;
   // whole-grid launches walk three running row pointers (+32 rows per tile); windowed ones look
   // the rows up in the table.
   const unsigned short *kq0 = qkv + (size_t)krow0 * ldq + kcol;
   const unsigned short *kq1 = qkv + (size_t)krow1 * ldq + kcol;
-  const unsigned short *vq = qkv + (size_t)vrow * ldq;
+  const unsigned short *vq0 = qkv + (size_t)krow0 * ldq + vcol;
+  const unsigned short *vq1 = qkv + (size_t)krow1 * ldq + vcol;
   const long tile_step = 32 * ldq;
 #define CRA5_ROW(JJ, ROW) \
   reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(qkv) + tab[(JJ)*32 + (ROW)])
@@ -170,14 +178,15 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
 #define CRA5_V_LOAD(J)                                                                    \
   {                                                                                       \
     if (GLOBAL) {                                                                         \
-      sv0 = *reinterpret_cast<const uint4 *>(vq + vcol0);                                 \
-      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(vq + vcol1);                        \
-      vq += ((J) < n_tiles - 1) ? tile_step : 0;                                          \
+      sv0 = *reinterpret_cast<const uint4 *>(vq0);                                        \
+      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(vq1);                               \
+      const long st_ = ((J) < n_tiles - 1) ? tile_step : 0;                               \
+      vq0 += st_;                                                                         \
+      vq1 += st_;                                                                         \
     } else {                                                                              \
       const int jj_ = min((J), n_tiles - 1);                                              \
-      const unsigned short *vr_ = CRA5_ROW(jj_, vrow);                                    \
-      sv0 = *reinterpret_cast<const uint4 *>(vr_ + vcol0);                                \
-      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(vr_ + vcol1);                       \
+      sv0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + vcol);                \
+      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + vcol);       \
     }                                                                                     \
   }
   // piece -> (chunk = piece>>3, plane = (piece>>2)&1, d0 = 32*chunk + 8*(piece&3))
@@ -195,18 +204,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   {                                                                                       \
     const int idx = tid + (P)*NT;                                                         \
     if (idx < PIECES) {                                                                   \
-      const int vrow = idx & 31, vpiece = idx >> 5;                                       \
-      const int vplane = (vpiece >> 2) & 1, vd0 = 32 * (vpiece >> 3) + 8 * (vpiece & 3);  \
-      unsigned short *vt = Vt + (BUF)*VBUF + vplane * VPL + vd0 * VS + vrow;              \
-      const unsigned int w0 = sv##P.x, w1 = sv##P.y, w2 = sv##P.z, w3 = sv##P.w;          \
-      vt[0 * VS] = (unsigned short)(w0 & 0xFFFFu);                                        \
-      vt[1 * VS] = (unsigned short)(w0 >> 16);                                            \
-      vt[2 * VS] = (unsigned short)(w1 & 0xFFFFu);                                        \
-      vt[3 * VS] = (unsigned short)(w1 >> 16);                                            \
-      vt[4 * VS] = (unsigned short)(w2 & 0xFFFFu);                                        \
-      vt[5 * VS] = (unsigned short)(w2 >> 16);                                            \
-      vt[6 * VS] = (unsigned short)(w3 & 0xFFFFu);                                        \
-      vt[7 * VS] = (unsigned short)(w3 >> 16);                                            \
+      const int row = idx >> 4, piece = idx & 15;                                         \
+      const int plane = (piece >> 2) & 1, d0 = 32 * (piece >> 3) + 8 * (piece & 3);       \
+      *reinterpret_cast<uint4 *>(Vt + (BUF)*VBUF + plane * VPL + row * VS + d0) = sv##P;  \
     }                                                                                     \
   }
 #define CRA5_V_STORE(BUF) { CRA5_V_STORE1(0, BUF) if (TWO) CRA5_V_STORE1(1, BUF) }
@@ -236,7 +236,14 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   }
 
   const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
-  const unsigned short *v_base = Vt + l31 * VS + 4 * h;          // + buf*VBUF + plane*VPL + 32*dt*VS + 16*t (+8)
+  // V^T fragments (A operand: row d = l31, 8 keys per lane) come out of the ROW-MAJOR V image through
+  // ds_read_b64_tr_b16: inside each 16-lane group, lane l' receives element (l' & 3) of the 8-byte
+  // slots addressed by lanes (l' >> 2) + {0, 4, 8, 12} (probed: tools/probes/tr_probe.hip).  Lane l'
+  // therefore ADDRESSES V[kbase + (l' >> 2)][d0 + 4 (l' & 3) ..+3] and RECEIVES V[kbase + 0..3][d0 + l'],
+  // d0 = 16 ((lane >> 4) & 1): four consecutive keys of its own d.  Row stride 192 B puts the four
+  // key rows x two d-halves of a 32-lane LDS cycle on 8 disjoint 8-bank ranges (conflict-free).
+  const unsigned short *v_base = Vt + (4 * h + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  // + buf*VBUF + plane*VPL + (16*t + 8*a)*VS + 32*dt
 
   // cross-half max: lanes l and l+32 own the two halves of one query's 32 scores
 #define CRA5_XHALF_MAX(X)                                                                 \
@@ -319,11 +326,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
       half8 vh[2], vl[2];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const unsigned short *vp = v_base + vb * VBUF + 32 * dt * VS + 16 * t;
-        const half4 a0 = *reinterpret_cast<const half4 *>(vp);
-        const half4 a1 = *reinterpret_cast<const half4 *>(vp + 8);
-        const half4 b0 = *reinterpret_cast<const half4 *>(vp + VPL);
-        const half4 b1 = *reinterpret_cast<const half4 *>(vp + VPL + 8);
+        const unsigned short *vp = v_base + vb * VBUF + 16 * t * VS + 32 * dt;
+        const half4 a0 = CRA5_TR_READ(vp);
+        const half4 a1 = CRA5_TR_READ(vp + 8 * VS);
+        const half4 b0 = CRA5_TR_READ(vp + VPL);
+        const half4 b1 = CRA5_TR_READ(vp + VPL + 8 * VS);
         vh[dt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
         vl[dt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
@@ -352,9 +359,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     // then start fetching K(j+3), V(j+2).
 #ifndef ATT_SKIP_STAGE
     CRA5_K_STORE(j & 1);
-#ifndef ATT_SKIP_VSTORE
     CRA5_V_STORE((j + 1) & 1);
-#endif
     CRA5_K_LOAD(j + 3);
     CRA5_V_LOAD(j + 2);
 #endif
@@ -419,7 +424,7 @@ extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp
 #define CRA5_ATT_GO(NWV, HIV, GLV) \
   return launch<NWV, HIV, GLV>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st)
 #ifndef ATT_NW_GLOBAL
-#define ATT_NW_GLOBAL 8   /* 256 queries share each K/V tile: half the staging of 4 waves (1.63 vs 1.71 ms) */
+#define ATT_NW_GLOBAL 12   /* 384 queries share each K/V tile (4 / 8 / 12 waves: 1.59 / 1.56 / 1.52 ms) */
 #endif
   if (whole) {
     if (hi_only) CRA5_ATT_GO(ATT_NW_GLOBAL, true, true);
