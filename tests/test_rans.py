@@ -123,6 +123,66 @@ def test_errors_are_codes_not_ub():
         ops.rans_encode(sym, good_idx[:3], cdf, lens, offs)
 
 
+def test_decoder_bucket_tables_wide_and_narrow_rows():
+    """The decoder's per-row bucket tables (csrc/host_entropy.cpp) against the oracle's linear scan:
+    rows from 2 bins to 3000 bins, bins of frequency 1 (many bins per bucket), every symbol of every
+    row hit at least once, decode into a caller-provided buffer."""
+    rng = np.random.default_rng(5)
+    rows = []
+    for n in (2, 3, 17, 64, 500, 3000):
+        p = np.full(n, 1e-9, np.float32)
+        hot = rng.integers(0, n, size=max(1, n // 8))
+        p[hot] = rng.random(hot.size).astype(np.float32) + 0.05
+        rows.append(cbind.pmf_to_cdf(p / p.sum()))
+    L = max(len(r) for r in rows)
+    cdf = np.zeros((len(rows), L), np.int32)
+    lens = np.zeros(len(rows), np.int32)
+    for i, r in enumerate(rows):
+        cdf[i, : len(r)] = r
+        lens[i] = len(r)
+    offs = np.zeros(len(rows), np.int32)
+    idx, sym = [], []
+    for i, r in enumerate(rows):
+        k = len(r) - 2                      # max_value: symbols 0..k-1 are regular, >= k escape
+        reg = np.arange(0, k)
+        idx += [i] * (reg.size + 3)
+        sym += reg.tolist() + [k, k + 5, -3]
+    idx, sym = np.array(idx, np.int32), np.array(sym, np.int32)
+    perm = rng.permutation(idx.size)
+    idx, sym = idx[perm], sym[perm]
+    a = ops.rans_encode(sym, idx, cdf, lens, offs)
+    assert a == cbind.rans_encode(sym, idx, cdf, lens, offs)
+    out = np.empty(idx.size, np.int32)
+    assert ops.rans_decode(a, idx, cdf, lens, offs, out=out) is out
+    assert np.array_equal(out, sym)
+    assert np.array_equal(cbind.rans_decode(a, idx, cdf, lens, offs).numpy(), sym)
+    with pytest.raises(ValueError):
+        ops.rans_decode(a, idx, cdf, lens, offs, out=np.empty(idx.size - 1, np.int32))
+    with pytest.raises(ValueError):
+        ops.rans_decode(a, idx, cdf, lens, offs, out=np.empty(idx.size, np.int64))
+
+
+def test_decoder_rejects_garbage_without_ub():
+    """Random bytes / a non-monotone table decode to an error code or to symbols, never to a crash."""
+    rng = np.random.default_rng(9)
+    cdf, lens, offs = _random_tables(rng, 3, 20)
+    idx = rng.integers(0, 3, size=500).astype(np.int32)
+    for k in range(20):
+        junk = rng.integers(0, 256, size=int(rng.integers(8, 400)), dtype=np.uint8).tobytes()
+        try:
+            ops.rans_decode(junk, idx, cdf, lens, offs)
+        except Cra5Error:
+            pass
+    bad = cdf.copy()
+    bad[0, 1], bad[0, 2] = bad[0, 2], bad[0, 1]      # not sorted: generic search path
+    sym = np.zeros(50, np.int32)
+    s = ops.rans_encode(sym, np.ones(50, np.int32), cdf, lens, offs)
+    try:
+        ops.rans_decode(s, np.zeros(50, np.int32), bad, lens, offs)
+    except Cra5Error:
+        pass
+
+
 def test_product_pmf_to_cdf_matches_reference(golden_dir):
     import json
     g = json.load(open(f"{golden_dir}/pmf_cdf.json"))
