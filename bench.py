@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (no sparsity)
 FLOP_PER_FRAME = 11.57e12      # encode 6.132 + decode 5.415 + hyper-prior
 
@@ -196,7 +197,10 @@ def main():
         "warmup_settle_frames": settle_frames,
         "bytes_per_frame": float(stats[:, 1:3].sum().item()) / max(total_frames, 1),
         "model_tflops": FLOP_PER_FRAME * fps / 1e12,
-        "mfma_fraction_end_to_end": FLOP_PER_FRAME * fps / world / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+        # whole-path algorithmic rate against the engine's MFMA ceiling (SURVEY 8d "report both")
+        "mfma_fraction_end_to_end": FLOP_PER_FRAME * fps / world / (
+            (PEAK_FP32_MFMA_TFLOPS if net.gemm_mode == "f32" else
+             PEAK_F16_MFMA_TFLOPS / (3.0 if net.precision == "fp32" else 1.0)) * 1e12),
     }
     def measured_traffic():
         """HBM-side bytes per gemm launch from the committed rocprofv3 PMC passes (FETCH_SIZE
@@ -241,6 +245,16 @@ def main():
                                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                                "traffic": None, "launches": g["launches"], "avg_launch_ms": g["ms"] / g["launches"],
                                "gemm_ms_per_step": g["ms"] * sample / steps}
+        mem = {}
+        for kind in ("layernorm", "im2col", "col2im"):
+            k = summ.get(kind)
+            if k and k["ms"] > 0:
+                gbs = k["work"] / (k["ms"] * 1e-3) / 1e9
+                mem[kind] = {"achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBPS, "launches": k["launches"],
+                             "ms_per_step": k["ms"] * sample / steps}
+        if mem:
+            out["hbm_bound_kernels"] = dict(mem, peak_GBps=PEAK_HBM_GBPS,
+                                            note="algorithmic bytes / HIP-event duration per launch; 8 TB/s HBM3E peak")
         a = summ.get("window_attention_split") or summ.get("window_attention_f32")
         if a and a["ms"] > 0:
             out["attention"] = {"kernel": "window_attention_split_kernel" if "window_attention_split" in summ

@@ -142,7 +142,17 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ c
 // writes 8*kh*kw consecutive K entries (3.5 KB runs).  HBM-bound: 1.11 GB in, 1.22 GB out.
 // ---------------------------------------------------------------------------------------
 constexpr int TILE_TOK = 16;
-constexpr int TILE_CH = 8;
+#ifndef CRA5_I2C_TILE_CH
+#define CRA5_I2C_TILE_CH 2
+#endif
+#ifndef CRA5_C2I_TILE_CH
+#define CRA5_C2I_TILE_CH 2
+#endif
+// channels per block: 8 -> 2 took the gather from 44 % to 54 % and the scatter from 31 % to 63 % of the
+// HBM peak (LDS per block 56 KB -> 14 KB: 2 -> 8 resident blocks per CU; tools/mem_bench.py).  Must stay
+// even: the K offset c0*KH*KW of a block has to be a multiple of 4 floats for the 16-byte accesses.
+constexpr int TILE_CH = CRA5_I2C_TILE_CH;      // gather (im2col)
+constexpr int TILE_CH_S = CRA5_C2I_TILE_CH;    // scatter (col2im)
 
 // LDS image of both kernels: token-major [16 tokens][8*KH*KW (+4 pad)] = the GEMM-side layout,
 // so the GEMM-side accesses are contiguous ds_read/write_b128 + 16-byte global accesses, and the
@@ -154,6 +164,7 @@ __global__ __launch_bounds__(256) void im2col_tiled_kernel(const float *__restri
                                                            int sh, int Hp, int Wp, int ldk) {
   constexpr int SEG = TILE_TOK * KW;             // floats per staged image-row segment
   constexpr int TS = TILE_CH * KH * KW + 4;      // LDS token stride (floats)
+  static_assert((TILE_CH * KH * KW) % 4 == 0, "a block's K offset must stay 16-byte aligned");
   __shared__ __attribute__((aligned(16))) float tile[TILE_TOK * TS];
   // block order: channel chunk fastest -> consecutive blocks sweep the K axis of the same 16
   // tokens (the 118 KB token rows of the column matrix are streamed front to back)
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256) void im2col_tiled_kernel(const float *__restri
   // ---- emit: contiguous K runs per token ----------------------------------------------------------
   const int kpt = nc * KH * KW;                  // K entries per token in this block
   const int q4 = (kpt + 3) / 4;
-  const int kbase = c0 * KH * KW;                // multiple of 4 (TILE_CH * KH * KW = 880)
+  const int kbase = c0 * KH * KW;                // multiple of 4 (TILE_CH * KH * KW = 220)
   for (int e = threadIdx.x; e < TILE_TOK * q4; e += 256) {
     const int t = e / q4, k4 = (e - t * q4) * 4;
     const float4 v = *reinterpret_cast<const float4 *>(tile + t * TS + k4);
@@ -225,20 +236,21 @@ __global__ __launch_bounds__(256) void col2im_tiled_kernel(const float *__restri
                                                            const float *__restrict__ stdv, float *__restrict__ x, int C,
                                                            int H, int W, int sh, int Hp, int Wp, int ldn) {
   constexpr int SEG = TILE_TOK * KW;
-  constexpr int TS = TILE_CH * KH * KW + 4;
+  constexpr int TS = TILE_CH_S * KH * KW + 4;
+  static_assert((TILE_CH_S * KH * KW) % 4 == 0, "a block's K offset must stay 16-byte aligned");
   __shared__ __attribute__((aligned(16))) float tile[TILE_TOK * TS];
   // the i = sh row of the patch row above lands on this block's first output row (overlap-add);
   // KH - sh == 1 is checked by the launcher
-  __shared__ __attribute__((aligned(16))) float above[TILE_CH * SEG];
+  __shared__ __attribute__((aligned(16))) float above[TILE_CH_S * SEG];
   // block order: channel chunk fastest -> consecutive blocks sweep the K axis of the same 16
   // tokens (the 118 KB token rows of the column matrix are streamed front to back)
   const int tiles_w = Wp / TILE_TOK;
-  const int n_cc = (C + TILE_CH - 1) / TILE_CH;
+  const int n_cc = (C + TILE_CH_S - 1) / TILE_CH_S;
   const int cc = blockIdx.x % n_cc;
   const int pwt = (blockIdx.x / n_cc) % tiles_w;
   const int ph = blockIdx.x / (n_cc * tiles_w);
-  const int c0 = cc * TILE_CH;
-  const int nc = min(TILE_CH, C - c0);
+  const int c0 = cc * TILE_CH_S;
+  const int nc = min(TILE_CH_S, C - c0);
   const int kpt = nc * KH * KW, q4 = (kpt + 3) / 4, kbase = c0 * KH * KW;
   // ---- stage this patch row: 3.5 KB token runs, straight copy ------------------------------------
   constexpr int UNR = 7;
@@ -266,8 +278,8 @@ __global__ __launch_bounds__(256) void col2im_tiled_kernel(const float *__restri
       }
     }
   }
-  if (ph > 0) {   // TILE_CH * SEG / 256 = 5 independent scalar loads per thread, issued together
-    constexpr int AU = (TILE_CH * SEG + 255) / 256;
+  if (ph > 0) {   // TILE_CH_S * SEG / 256 = 5 independent scalar loads per thread, issued together
+    constexpr int AU = (TILE_CH_S * SEG + 255) / 256;
     float av[AU];
 #pragma unroll
     for (int q = 0; q < AU; ++q) {
@@ -533,7 +545,7 @@ int cra5_col2im_f32(const float *cols, const float *mean, const float *stdv, flo
   if ((mean == nullptr) != (stdv == nullptr)) return CRA5_ERR_ARG;
   if (kh == 11 && kw == 10 && sw == 10 && sh == 10 && Wp % TILE_TOK == 0 && (W % 4) == 0 && (ldn % 4) == 0 &&
       ((uintptr_t)cols & 15) == 0 && ((uintptr_t)x & 15) == 0) {
-    const int blocks = (Wp / TILE_TOK) * Hp * ((C + TILE_CH - 1) / TILE_CH);
+    const int blocks = (Wp / TILE_TOK) * Hp * ((C + TILE_CH_S - 1) / TILE_CH_S);
     hipLaunchKernelGGL((col2im_tiled_kernel<11, 10>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, cols, mean,
                        stdv, x, C, H, W, sh, Hp, Wp, ldn);
     return (int)hipGetLastError();

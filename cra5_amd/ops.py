@@ -199,11 +199,14 @@ def layernorm(x, gamma, beta, eps=1e-6, out=None, out_split=None, want_f32=True)
         out = torch.empty((rows, D), device=x.device, dtype=torch.float32)
     if out_split is not None:
         assert out_split.rows == rows and out_split.K == D
+    ev = TIMER.start() if TIMER is not None else None
     check(lib().cra5_layernorm_f32(_p(x), _row_stride(x), _p(gamma), _p(beta), _p(out),
                                    _row_stride(out) if out is not None else 0,
                                    _p(out_split.data) if out_split is not None else None,
                                    out_split.Kp if out_split is not None else 0, rows, D, float(eps), _stream()),
           "cra5_layernorm_f32")
+    if ev is not None:   # bytes: the row read once + every output written once
+        TIMER.stop("layernorm", ev, 4.0 * rows * D * (1 + (out is not None) + (out_split is not None)))
     return out if out is not None else out_split
 
 
@@ -273,8 +276,11 @@ def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split
     assert x.is_contiguous()
     if out_split is not None:
         assert out_split.rows == Hp * Wp and out_split.K == K
+        ev = TIMER.start() if TIMER is not None else None
         check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), None, _p(out_split.data), C, H, W, kh, kw, sh, sw, Hp,
                                     Wp, out_split.Kp, _stream()), "cra5_im2col_f32")
+        if ev is not None:   # bytes: the frame read once + the patch matrix written once
+            TIMER.stop("im2col", ev, 4.0 * C * H * W + 4.0 * Hp * Wp * K)
         return out_split
     ldk = ldk or K
     if out is None:
@@ -291,8 +297,11 @@ def col2im(cols, C, kh, kw, sh, sw, Hp, Wp, mean=None, std=None, out=None):
     if out is None:
         out = torch.empty((C, H, W), device=cols.device, dtype=torch.float32)
     assert out.is_contiguous()
+    ev = TIMER.start() if TIMER is not None else None
     check(lib().cra5_col2im_f32(_p(cols), _p(mean), _p(std), _p(out), C, H, W, kh, kw, sh, sw, Hp, Wp,
                                 _row_stride(cols), _stream()), "cra5_col2im_f32")
+    if ev is not None:   # bytes: the column matrix read once + the frame written once
+        TIMER.stop("col2im", ev, 4.0 * Hp * Wp * C * kh * kw + 4.0 * C * H * W)
     return out
 
 
