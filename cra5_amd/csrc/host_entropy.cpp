@@ -102,24 +102,36 @@ struct Encoder {
 int encode_impl(const int32_t *symbols, const int32_t *indexes, size_t n, const Tables &t,
                 uint8_t **out, size_t *out_len) {
   if (!out || !out_len || (n && (!symbols || !indexes))) return CRA5_ERR_ARG;
-  // pass 1: validate + count coded sub-symbols (each emits at most one word)
-  size_t n_sub = 0;
-  for (size_t i = 0; i < n; ++i) {
-    const int32_t ci = indexes[i];
-    if (ci < 0 || ci >= t.n_cdfs || t.sizes[ci] < 2 || t.sizes[ci] > t.stride) return CRA5_ERR_INDEX;
-    const Resolved r = resolve(t, symbols[i], ci);
-    n_sub += 1;
-    if (r.escape) n_sub += static_cast<size_t>(r.n_nibbles) / kBypassMax + 1 + r.n_nibbles;
-  }
-  const size_t cap = n_sub + 2;
+  // One pass, last symbol first.  Every coded sub-symbol emits at most one 32-bit word and a symbol
+  // has at most 1 bin + 1 count nibble + 8 payload nibbles (a uint32 payload), so 10 n + 2 words always
+  // suffice; the words are written from the END of the buffer, only the pages actually reached are
+  // ever touched (a frame: 106 MB reserved, ~4 MB used).  If that reservation fails, count first.
+  size_t cap = 10 * n + 2;
   uint32_t *buf = static_cast<uint32_t *>(std::malloc(cap * sizeof(uint32_t)));
-  if (!buf) return CRA5_ERR_ALLOC;
+  if (!buf) {
+    size_t n_sub = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const int32_t ci = indexes[i];
+      if (ci < 0 || ci >= t.n_cdfs || t.sizes[ci] < 2 || t.sizes[ci] > t.stride) return CRA5_ERR_INDEX;
+      const Resolved r = resolve(t, symbols[i], ci);
+      n_sub += 1;
+      if (r.escape) n_sub += static_cast<size_t>(r.n_nibbles) / kBypassMax + 1 + r.n_nibbles;
+    }
+    cap = n_sub + 2;
+    buf = static_cast<uint32_t *>(std::malloc(cap * sizeof(uint32_t)));
+    if (!buf) return CRA5_ERR_ALLOC;
+  }
   Encoder e;
   e.ptr = buf + cap;
-  // pass 2: last symbol first; inside a symbol the reference pushes
-  // [bin, count nibbles (15,15,..,rem), payload nibbles lsb-first] and pops in reverse.
+  // inside a symbol the reference pushes [bin, count nibbles (15,15,..,rem), payload nibbles
+  // lsb-first] and pops in reverse.
   for (size_t i = n; i-- > 0;) {
-    const Resolved r = resolve(t, symbols[i], indexes[i]);
+    const int32_t ci = indexes[i];
+    if (ci < 0 || ci >= t.n_cdfs || t.sizes[ci] < 2 || t.sizes[ci] > t.stride) {
+      std::free(buf);
+      return CRA5_ERR_INDEX;
+    }
+    const Resolved r = resolve(t, symbols[i], ci);
     if (r.escape) {
       for (int j = r.n_nibbles - 1; j >= 0; --j) e.put_bits((r.raw >> (j * kBypassBits)) & kBypassMax);
       const uint32_t full = static_cast<uint32_t>(r.n_nibbles) / kBypassMax;
