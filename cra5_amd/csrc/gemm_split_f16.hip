@@ -21,14 +21,16 @@
 //
 // Kernel structure: tiles of 256x256 / 192x256 (8 waves = 2 per SIMD, 4x2 / 3x2 32x32
 // accumulators per wave) or 128x128 / 64x64 (4 waves) chosen per shape; two LDS stages of
-// the 4 plane tiles (A hi/lo, W hi/lo), one barrier per BK = 32 step: tile k+1 goes from
-// registers to the idle stage and tile k+2 is fetched from L2/HBM while tile k is consumed;
-// 64-byte LDS rows with an XOR swizzle of the 16-byte piece index (conflict-free
-// ds_read_b128 without padding, so 256x256 double-buffered fits in 128 KB); MFMAs issued
-// plane-major (TM*TN independent accumulators between dependent MFMAs); XCD-aware tile
-// order; fused bias / exact-erf GELU / residual epilogue with fp32 and/or split-f16
-// output.  Long reductions (K > 8192: the patch-embed conv, K = 29 480) are chained through
-// the fp32 output in chunks of <= 8192 (two-level sum).
+// [A rows | W rows], 128 B per row per k-step, filled by LDS-DMA (global_load_lds_dwordx4,
+// one cache line per row, XOR swizzle of the 16-byte piece index applied on the source
+// side -> conflict-free ds_read_b128 without padding, 256x256 double-buffered = 128 KB);
+// ONE barrier per BK = 32 step placed between the step's two 16-wide halves, with the next
+// tile's first-half fragments prefetched across it, so the matrix pipe never waits on the
+// barrier; MFMAs issued plane-major (TM*TN independent accumulators between dependent
+// MFMAs); XCD-aware tile order; epilogue through wave-private LDS (row-contiguous float4
+// accesses) with fused bias / erf-GELU / residual and fp32 and/or split-f16 output.  Long
+// reductions (K > 8192: the patch-embed conv, K = 29 480) are chained through the fp32
+// output in chunks of <= 8192 (two-level sum).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -41,7 +43,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int BK = 32;         // elements per k-step
-constexpr int ROW_H = 32;      // LDS row = 64 B = 4 x 16-byte pieces (XOR-swizzled, no padding)
 
 // gelu(x) = x * Phi(x),  Phi(x) = 0.5 erfc(-x / sqrt 2),  erfc(t) = exp(-t^2) * k P(k), k = 1/(1 + 0.4 t)
 // for t >= 0 (degree-7 least-squares fit, |erfc error| <= 8.3e-9 on [0, 6]; evaluated in fp32 the
@@ -92,11 +93,10 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   constexpr int A_P = BM / ROWS_PER_PASS;
   constexpr int B_P = BN / ROWS_PER_PASS;
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/threads mismatch");
-  constexpr int STAGE = (2 * BM + 2 * BN) * ROW_H;  // halves per pipeline stage
+  constexpr int STAGE = (BM + BN) * 64;  // halves per pipeline stage: 128 B per row
 
-  // two stages of [A hi][A lo][W hi][W lo]; rows are 64 B (4 x 16-byte pieces), piece p of row r
-  // lives at physical piece p ^ ((r >> 2) & 3): every ds_read_b128 lane group (16 rows, one
-  // logical piece) then touches 16 distinct 16-byte slots - conflict-free without padding.
+  // two stages of [A rows][W rows], 128 B per row = [32 hi | 32 lo] of one k-step, XOR-swizzled in
+  // 16-byte pieces (see the staging comment below); 2 x (BM + BN) x 128 B, no padding.
   __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE];
 
   CRA5_TRACE(0);
@@ -112,32 +112,33 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  // Staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 16 rows x 64 B of one
-  // plane straight into LDS - no staging VGPRs, no ds_write pass (ds_write_b128 runs at ~79 B/clk,
-  // it was ~830 exposed cycles per k-step).  The destination is wave-uniform base + lane*16, i.e.
-  // LINEAR: row = lane/4, physical piece = lane%4; the XOR swizzle is therefore applied to the
-  // per-lane SOURCE address: lane fetches logical piece (lane%4) ^ ((row>>2)&3) = (lane&3)^(lane>>4).
-  // A stage is [A hi][A lo][W hi][W lo] = (2BM + 2BN)/16 one-KB groups, dealt round-robin to
-  // the waves.  Rows past M / N are clamped to the last row (duplicates, never stored).
+  // Staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 1 KB straight into LDS -
+  // no staging VGPRs, no ds_write pass.  The destination is wave-uniform base + lane*16, i.e. LINEAR
+  // (row = lane/8, physical piece = lane%8), so the XOR swizzle is applied to the per-lane SOURCE
+  // address.  A stage is [A rows][W rows] = (BM + BN)/8 one-KB groups, dealt round-robin to the waves.
+  // Rows past M / N are clamped to the last row (duplicates, never stored).
   constexpr int GROUPS = (2 * BM + 2 * BN) / 16;
   constexpr int NWAVE = WM * WN;
   static_assert(GROUPS % NWAVE == 0, "groups must divide evenly over the waves");
   constexpr int IPW = GROUPS / NWAVE;      // LDS-DMA instructions per wave per k-step
   const unsigned short *src[IPW];
+  // One instruction = 8 rows x 128 B: a row's [32 hi | 32 lo] chunk is one cache line, requested once
+  // (16 rows x 64 B of one plane per instruction asked for every line twice: -3..6 % on the 192x256 tiles).  LDS rows are
+  // 128 B = 8 pieces [hi 0-3 | lo 4-7]; piece p of row r lives at physical piece p ^ ((r >> 1) & 7):
+  // the 16 rows of a ds_read_b128 lane group then hit 16 distinct 16-byte slots of the 256-B bank row.
   {
-    const int lrow = lane >> 2, lpiece = (lane & 3) ^ (lane >> 4);
+    const int lrow = lane >> 3;
 #pragma unroll
     for (int q = 0; q < IPW; ++q) {
-      const int gid = wave + q * NWAVE;          // group id inside the stage
-      const int grow = gid * 16;                 // first row of the group in [A hi | A lo | W hi | W lo]
-      const bool isA = grow < 2 * BM;
-      const int rr = isA ? grow : grow - 2 * BM;
-      const int plane_ = isA ? (rr >= BM) : (rr >= BN);
-      const int row_ = (isA ? rr - plane_ * BM : rr - plane_ * BN) + lrow;
+      const int gid = wave + q * NWAVE;          // 8 rows of [A rows | W rows]
+      const int grow = gid * 8;
+      const bool isA = grow < BM;
+      const int row_ = (isA ? grow : grow - BM) + lrow;
+      const int lpiece = (lane & 7) ^ ((row_ >> 1) & 7);
       if (isA)
-        src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + plane_ * 32 + lpiece * 8;
+        src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + lpiece * 8;
       else
-        src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + plane_ * 32 + lpiece * 8;
+        src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + lpiece * 8;
     }
   }
   // (the builtin only exists in the device pass; the host pass just needs the launch stub)
@@ -166,24 +167,28 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
         if (LONGK) master[i][j][r] = 0.f;
       }
 
-  // fragment read offsets (halves) inside a stage: row * 32 + ((2*kk + h) ^ sw) * 8
-  const int sw = (l31 >> 2) & 3;
-  const int a_row = (wm * TM * 32 + l31) * ROW_H;
-  const int b_row = 2 * BM * ROW_H + (wn * TN * 32 + l31) * ROW_H;
-  int poff[2];
+  // fragment read offsets (halves) inside a stage: row * 64 + (piece ^ sw) * 8, piece = 2*kk + h (hi)
+  // or 4 + 2*kk + h (lo); sw = (row >> 1) & 7 = (l31 >> 1) & 7 (sub-tile bases are multiples of 32 rows)
+  const int sw = (l31 >> 1) & 7;
+  const int a_row = (wm * TM * 32 + l31) * 64;
+  const int b_row = BM * 64 + (wn * TN * 32 + l31) * 64;
+  int poff[2], poff_lo[2];
   poff[0] = ((0 + h) ^ sw) << 3;
   poff[1] = ((2 + h) ^ sw) << 3;
+  poff_lo[0] = ((4 + h) ^ sw) << 3;
+  poff_lo[1] = ((6 + h) ^ sw) << 3;
+  constexpr int A_LO = 0, B_LO = 0, SUB = 32 * 64;
 
   // fragments of one 16-wide k-half (KK = 0 | 1) of stage ST
 #define CRA5_FRAG_READ(AH, AL, BH, BL, ST, KK)                                                 \
   {                                                                                            \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                           \
-      AH[i] = *reinterpret_cast<const half8 *>((ST) + a_row + i * 32 * ROW_H + poff[KK]);      \
-      if (NPROD == 3) AL[i] = *reinterpret_cast<const half8 *>((ST) + a_row + BM * ROW_H + i * 32 * ROW_H + poff[KK]); \
+      AH[i] = *reinterpret_cast<const half8 *>((ST) + a_row + i * SUB + poff[KK]);             \
+      if (NPROD == 3) AL[i] = *reinterpret_cast<const half8 *>((ST) + a_row + A_LO + i * SUB + poff_lo[KK]); \
     }                                                                                          \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
-      BH[j] = *reinterpret_cast<const half8 *>((ST) + b_row + j * 32 * ROW_H + poff[KK]);      \
-      if (NPROD == 3) BL[j] = *reinterpret_cast<const half8 *>((ST) + b_row + BN * ROW_H + j * 32 * ROW_H + poff[KK]); \
+      BH[j] = *reinterpret_cast<const half8 *>((ST) + b_row + j * SUB + poff[KK]);             \
+      if (NPROD == 3) BL[j] = *reinterpret_cast<const half8 *>((ST) + b_row + B_LO + j * SUB + poff_lo[KK]); \
     }                                                                                          \
   }
   // small terms first, plane-major: TM*TN independent accumulators between dependent MFMAs.
