@@ -343,3 +343,27 @@ def test_thin_batch_of_two_frames(thin, dev):
     for b in range(2):
         one = thin.decompress([[out["strings"][0][b]], [out["strings"][1][b]]], out["z_shape"])["x_hat"]
         assert torch.equal(one[0], rec[b])
+
+
+def test_frame_pipeline_scheduling_is_transparent(thin, dev):
+    """Frames in flight, GPU-phase slots and exclusive phases only change WHEN kernels run: every
+    frame's byte streams and reconstruction equal the serial single-frame result, in order."""
+    from cra5_amd.pipeline import FramePipeline
+    frames = [synth.synth_frame(thin.cfg['in_chans'], seed=s).unsqueeze(0).to(dev) for s in (2, 9, 4)]
+    ref = []
+    for f in frames:
+        out = thin.compress(f)
+        ref.append((out["strings"], thin.decompress(out["strings"], out["z_shape"])["x_hat"]))
+    keep = (thin.gpu_exclusive, thin.gpu_slots)
+    pipe = FramePipeline(thin, workers=4)
+    try:
+        for excl, slots in ((False, 0), (False, 2), (True, 0)):
+            thin.gpu_exclusive, thin.gpu_slots = excl, slots
+            res = pipe.roundtrip([frames[i % 3] for i in range(7)])
+            for i, (out, x_hat) in enumerate(res):
+                strings, x_ref = ref[i % 3]
+                assert out["strings"] == strings
+                assert torch.equal(x_hat, x_ref)
+    finally:
+        thin.gpu_exclusive, thin.gpu_slots = keep
+        pipe.close()
