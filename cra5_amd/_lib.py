@@ -17,6 +17,7 @@ SIGNATURES = {
     "cra5_abi_version": (c_int, []),
     "cra5_rans_encode_with_indexes": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                               P(c_void_p), P(c_size_t)]),
+    "cra5_rans_encode_resolved": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, P(c_void_p), P(c_size_t)]),
     "cra5_rans_decode_with_indexes": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p,
                                               c_void_p, c_void_p]),
     "cra5_rans_encode_batch": (c_int, [c_int, P(c_void_p), P(c_void_p), P(c_size_t), P(c_void_p), P(c_int), P(c_int),
@@ -54,6 +55,8 @@ SIGNATURES = {
                                               c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cra5_entropy_bottleneck_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                             c_void_p, c_int, c_int, c_void_p]),
+    "cra5_rans_resolve_symbols_i32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "cra5_gdn_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cra5_event_create": (c_int, [P(c_void_p)]),
     "cra5_event_record": (c_int, [c_void_p, c_void_p]),

@@ -401,6 +401,47 @@ __global__ __launch_bounds__(256) void gaussian_conditional_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Symbol -> (start, range, escape payload) against the quantised CDF tables, on the device
+// (rans_interface.cpp:121-150; the host encoder then only updates its state).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resolve_symbols_kernel(
+    const int32_t *__restrict__ sym, const int32_t *__restrict__ idx, size_t n, const int32_t *__restrict__ cdfs,
+    int n_cdfs, int stride, const int32_t *__restrict__ sizes, const int32_t *__restrict__ offsets,
+    uint32_t *__restrict__ sr, uint32_t *__restrict__ raw, uint8_t *__restrict__ esc) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int ci = idx[e];
+    if (ci < 0 || ci >= n_cdfs || sizes[ci] < 2 || sizes[ci] > stride) {
+      sr[e] = 0u;
+      raw[e] = 0u;
+      esc[e] = 255;
+      continue;
+    }
+    const int32_t *cdf = cdfs + (size_t)ci * stride;
+    const int max_value = sizes[ci] - 2;
+    int value = sym[e] - offsets[ci];
+    uint32_t r = 0u;
+    if (value < 0) {
+      r = (uint32_t)(-2 * value - 1);
+      value = max_value;
+    } else if (value >= max_value) {
+      r = (uint32_t)(2 * (value - max_value));
+      value = max_value;
+    }
+    const uint32_t start = (uint32_t)cdf[value] & 0xFFFFu;
+    const uint32_t range = (uint32_t)(cdf[value + 1] - cdf[value]) & 0xFFFFu;
+    sr[e] = start | (range << 16);
+    raw[e] = r;
+    uint8_t ec = 0;
+    if (value == max_value) {
+      int nn = 0;
+      while (nn < 8 && (r >> (4 * nn)) != 0u) ++nn;
+      ec = (uint8_t)(nn + 1);
+    }
+    esc[e] = ec;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // EntropyBottleneck (entropy_models.py:434-510).  Per-channel parameter block (58 floats):
 //   [ 0: 3) sp(M0)   [ 3: 6) b0   [ 6: 9) th(f0)
 //   [ 9:18) sp(M1)   [18:21) b1   [21:24) th(f1)
@@ -588,6 +629,16 @@ int cra5_entropy_bottleneck_f32(const float *z, const int32_t *sym_in, const flo
   if (lik && !params) return CRA5_ERR_ARG;
   hipLaunchKernelGGL(entropy_bottleneck_kernel, dim3(grid_for((size_t)C * n_per_ch)), dim3(256), 0,
                      (hipStream_t)stream, z, sym_in, medians, params, lik_bound, sym, z_hat, lik, C, n_per_ch);
+  return (int)hipGetLastError();
+}
+
+int cra5_rans_resolve_symbols_i32(const int32_t *symbols, const int32_t *indexes, size_t n, const int32_t *cdfs,
+                                  int n_cdfs, int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets,
+                                  uint32_t *start_range, uint32_t *raw, uint8_t *esc, void *stream) {
+  if (!symbols || !indexes || !cdfs || !cdf_sizes || !offsets || !start_range || !raw || !esc) return CRA5_ERR_ARG;
+  if (n == 0 || n_cdfs <= 0 || cdf_stride < 2) return CRA5_ERR_ARG;
+  hipLaunchKernelGGL(resolve_symbols_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, symbols, indexes, n,
+                     cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets, start_range, raw, esc);
   return (int)hipGetLastError();
 }
 

@@ -330,6 +330,50 @@ int cra5_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes
   return encode_impl(symbols, indexes, n, Tables{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets}, out, out_len);
 }
 
+int cra5_rans_encode_resolved(const uint32_t *start_range, const uint32_t *raw, const uint8_t *esc, size_t n,
+                              uint8_t **out, size_t *out_len) {
+  if (!out || !out_len || (n && (!start_range || !raw || !esc))) return CRA5_ERR_ARG;
+  const size_t cap = 10 * n + 2;   // see encode_impl
+  uint32_t *buf = static_cast<uint32_t *>(std::malloc(cap * sizeof(uint32_t)));
+  if (!buf) return CRA5_ERR_ALLOC;
+  Encoder e;
+  e.ptr = buf + cap;
+  for (size_t i = n; i-- > 0;) {
+    const uint32_t sr = start_range[i];
+    const uint32_t ec = esc[i];
+    if (ec) {
+      if (ec > 9) {
+        std::free(buf);
+        return CRA5_ERR_INDEX;
+      }
+      const int n_nibbles = static_cast<int>(ec) - 1;
+      const uint32_t r = raw[i];
+      for (int j = n_nibbles - 1; j >= 0; --j) e.put_bits((r >> (j * kBypassBits)) & kBypassMax);
+      e.put_bits(static_cast<uint32_t>(n_nibbles));   // n_nibbles <= 8 < 15: one count nibble
+    }
+    const uint32_t freq = sr >> 16;
+    if (!freq) {   // a zero-width bin cannot be coded (malformed table)
+      std::free(buf);
+      return CRA5_ERR_INDEX;
+    }
+    e.put(sr & 0xFFFFu, freq);
+  }
+  e.ptr -= 2;  // Rans64EncFlush
+  e.ptr[0] = static_cast<uint32_t>(e.x);
+  e.ptr[1] = static_cast<uint32_t>(e.x >> 32);
+  const size_t nbytes = static_cast<size_t>((buf + cap) - e.ptr) * sizeof(uint32_t);
+  uint8_t *res = static_cast<uint8_t *>(std::malloc(nbytes));
+  if (!res) {
+    std::free(buf);
+    return CRA5_ERR_ALLOC;
+  }
+  std::memcpy(res, e.ptr, nbytes);
+  std::free(buf);
+  *out = res;
+  *out_len = nbytes;
+  return CRA5_OK;
+}
+
 int cra5_rans_decode_with_indexes(const uint8_t *encoded, size_t len, const int32_t *indexes, size_t n,
                                   const int32_t *cdfs, int n_cdfs, int cdf_stride,
                                   const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out) {

@@ -404,6 +404,46 @@ def rans_encode(symbols, indexes, cdf, cdf_len, offsets):
         lib().cra5_free(out)
 
 
+def rans_resolve_symbols(symbols, indexes, cdf, cdf_len, offsets, out=None):
+    """Device side of the resolved encoder: int32 DEVICE tensors symbols / indexes [n], tables
+    cdf [n_cdfs, stride], cdf_len, offsets -> (start_range uint32-as-int32 [n], raw [n], esc uint8 [n])."""
+    for t in (symbols, indexes, cdf, cdf_len, offsets):
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise TypeError("rans_resolve_symbols takes contiguous int32 device tensors")
+    n = symbols.numel()
+    if indexes.numel() != n:
+        raise ValueError("`symbols` and `indexes` should have the same size.")
+    if out is None:
+        out = (torch.empty(n, device=symbols.device, dtype=torch.int32),
+               torch.empty(n, device=symbols.device, dtype=torch.int32),
+               torch.empty(n, device=symbols.device, dtype=torch.uint8))
+    sr, raw, esc = out
+    check(lib().cra5_rans_resolve_symbols_i32(_p(symbols), _p(indexes), n, _p(cdf), cdf.shape[0], cdf.shape[1],
+                                              _p(cdf_len), _p(offsets), _p(sr), _p(raw),
+                                              ctypes.c_void_p(esc.data_ptr()), _stream()),
+          "cra5_rans_resolve_symbols_i32")
+    return sr, raw, esc
+
+
+def rans_encode_resolved(start_range, raw, esc):
+    """-> bytes, from HOST arrays (numpy / CPU tensors): start_range, raw 32-bit words, esc uint8."""
+    def _np(a, dt):
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        return np.ascontiguousarray(a).view(dt) if a.dtype.itemsize == np.dtype(dt).itemsize else np.ascontiguousarray(a, dtype=dt)
+    s, r, e = _np(start_range, np.uint32).reshape(-1), _np(raw, np.uint32).reshape(-1), _np(esc, np.uint8).reshape(-1)
+    if not (s.size == r.size == e.size):
+        raise ValueError("start_range, raw and esc must have the same size")
+    out = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    check(lib().cra5_rans_encode_resolved(s.ctypes.data, r.ctypes.data, e.ctypes.data, s.size, ctypes.byref(out),
+                                          ctypes.byref(n)), "cra5_rans_encode_resolved")
+    try:
+        return ctypes.string_at(out.value, n.value)
+    finally:
+        lib().cra5_free(out)
+
+
 def rans_decode(data, indexes, cdf, cdf_len, offsets, out=None):
     """-> int32 numpy array of len(indexes) (written into `out`, a contiguous int32 array of that
     size, when given: e.g. the numpy view of a pinned staging tensor)."""

@@ -282,6 +282,8 @@ class VAEformer(nn.Module):
         # keeps a kernel's tail filled by another frame's blocks without letting ALL frames fall
         # into the host (rANS) phase together, which idles the GPU.  0 = unlimited.
         self.gpu_slots = int(os.environ.get("CRA5_GPU_SLOTS", "3"))
+        # y symbols are resolved against the CDF tables by a device kernel (same byte stream)
+        self.resolve_on_gpu = os.environ.get("CRA5_RESOLVE_GPU", "1") != "0"
         self._gpu_sem = None
         # the ~1 ms h_s phase between the two host phases of a decode does not queue for a slot
         self.light_bypass = os.environ.get("CRA5_LIGHT_BYPASS", "1") != "0"
@@ -707,11 +709,22 @@ class VAEformer(nn.Module):
                 y = self._encode_y_frame(x, mean=mean, std=std)
             s = self._latent_side_frame(y.contiguous())
             z_sym = self._to_host("z_sym", s["z_sym"])
-            y_sym = self._to_host("y_sym", s["y_sym"])
-            idx = self._to_host("idx", s["idx"])
+            gc = self.gaussian_conditional
+            if self.resolve_on_gpu:
+                # symbol -> (start, range, escape payload) against the CDF tables on the device
+                # (SURVEY 8f-2): the host coder below is a pure state-update loop
+                sr, raw, esc = ops.rans_resolve_symbols(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
+                                                        gc._quantized_cdf, gc._cdf_length, gc._offset)
+                sr, raw, esc = self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc)
+            else:
+                y_sym = self._to_host("y_sym", s["y_sym"])
+                idx = self._to_host("idx", s["idx"])
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
         z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
-        y_str = self.gaussian_conditional.encode_symbols(y_sym.numpy().reshape(-1), idx.numpy().reshape(-1))
+        if self.resolve_on_gpu:
+            y_str = ops.rans_encode_resolved(sr.numpy(), raw.numpy(), esc.numpy())
+        else:
+            y_str = gc.encode_symbols(y_sym.numpy().reshape(-1), idx.numpy().reshape(-1))
         return y_str, z_str
 
     @torch.no_grad()

@@ -48,6 +48,15 @@ int cra5_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes
                                   const int32_t *cdf_sizes, const int32_t *offsets,
                                   uint8_t **out, size_t *out_len);
 
+/* The same encoder fed with symbols ALREADY resolved against their tables (the table
+ * lookups move to the GPU, cra5_rans_resolve_symbols_i32 below, the host loop is pure state update).
+ * start_range[i] = start | range << 16 of the bin (the escape bin for out-of-range symbols);
+ * esc[i] = 0 for a regular symbol, 1 + number of 4-bit payload nibbles (1..9) for an escape whose
+ * payload is raw[i] (rans_interface.cpp:121-150), 255 = invalid index (-> CRA5_ERR_INDEX).
+ * Produces byte-for-byte the stream of cra5_rans_encode_with_indexes. */
+int cra5_rans_encode_resolved(const uint32_t *start_range, const uint32_t *raw, const uint8_t *esc, size_t n,
+                              uint8_t **out, size_t *out_len);
+
 /* RansDecoder.decode_with_indexes (rans_interface.cpp:215-284). `out` has n slots.
  * Unlike the reference (which reads past the end of a corrupt stream) a truncated
  * stream returns CRA5_ERR_STREAM. */
@@ -220,6 +229,13 @@ int cra5_entropy_bottleneck_f32(const float *z, const int32_t *sym_in, const flo
 /* GDN / IGDN (cra5/models/compressai/layers/gdn.py:76-92): x, y: [B][C][HW];
  * y = x * rsqrt(beta[i] + sum_j gamma[i][j] x_j^2)   (inverse: * sqrt).
  * beta / gamma are the re-parametrised (effective) values. */
+/* Device side of cra5_rans_encode_resolved: symbols / indexes / tables are DEVICE pointers (the
+ * model's _quantized_cdf [n_cdfs][cdf_stride], _cdf_length, _offset buffers); writes start_range,
+ * raw and esc (n entries each) as described there.  rans_interface.cpp:121-150 per element. */
+int cra5_rans_resolve_symbols_i32(const int32_t *symbols, const int32_t *indexes, size_t n, const int32_t *cdfs,
+                                  int n_cdfs, int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets,
+                                  uint32_t *start_range, uint32_t *raw, uint8_t *esc, void *stream);
+
 int cra5_gdn_f32(const float *x, const float *beta, const float *gamma, float *y, int B, int C,
                  int HW, int inverse, void *stream);
 

@@ -367,3 +367,21 @@ def test_frame_pipeline_scheduling_is_transparent(thin, dev):
     finally:
         thin.gpu_exclusive, thin.gpu_slots = keep
         pipe.close()
+
+
+def test_gpu_resolved_encoder_same_stream(thin, big, dev):
+    """Resolving the y symbols against the CDF tables on the device (cra5_rans_resolve_symbols_i32 +
+    cra5_rans_encode_resolved) writes exactly the stream of the table-driven host encoder, on the thin
+    model and on the full-size one (escape-heavy: half of its symbols sit in the narrowest row)."""
+    for net, C in ((thin, thin.cfg['in_chans']), (big, 268)):
+        x = synth.synth_frame(C, seed=11).unsqueeze(0).to(dev)
+        keep = net.resolve_on_gpu
+        try:
+            net.resolve_on_gpu = True
+            a = net.compress(x)
+            net.resolve_on_gpu = False
+            b = net.compress(x)
+        finally:
+            net.resolve_on_gpu = keep
+        assert a["strings"][0][0] == b["strings"][0][0] and a["strings"][1][0] == b["strings"][1][0]
+        assert len(a["strings"][0][0]) > 1000

@@ -162,6 +162,54 @@ def test_decoder_bucket_tables_wide_and_narrow_rows():
         ops.rans_decode(a, idx, cdf, lens, offs, out=np.empty(idx.size, np.int64))
 
 
+def _np_resolve(sym, idx, cdf, lens, offs):
+    """numpy restatement of the resolve step (rans_interface.cpp:121-150)."""
+    sr = np.zeros(sym.size, np.uint32)
+    raw = np.zeros(sym.size, np.uint32)
+    esc = np.zeros(sym.size, np.uint8)
+    for i in range(sym.size):
+        ci = int(idx[i])
+        mx = int(lens[ci]) - 2
+        v = int(sym[i]) - int(offs[ci])
+        r = 0
+        if v < 0:
+            r, v = -2 * v - 1, mx
+        elif v >= mx:
+            r, v = 2 * (v - mx), mx
+        start = int(cdf[ci, v]) & 0xFFFF
+        rng_ = (int(cdf[ci, v + 1]) - int(cdf[ci, v])) & 0xFFFF
+        sr[i] = start | (rng_ << 16)
+        raw[i] = r
+        if v == mx:
+            nn = 0
+            while nn < 8 and (r >> (4 * nn)) != 0:
+                nn += 1
+            esc[i] = nn + 1
+    return sr, raw, esc
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_resolved_encoder_writes_the_same_stream(seed):
+    """cra5_rans_encode_resolved (symbols resolved against the tables beforehand - on the GPU in the
+    product) == cra5_rans_encode_with_indexes, byte for byte, incl. escapes with 0..8 payload nibbles."""
+    rng = np.random.default_rng(100 + seed)
+    cdf, lens, offs = _random_tables(rng, int(rng.integers(1, 9)), int(rng.integers(3, 60)))
+    n = int(rng.integers(1, 3000))
+    idx = rng.integers(0, cdf.shape[0], size=n).astype(np.int32)
+    sym = rng.integers(-40, 40, size=n).astype(np.int32)
+    sym[::7] = rng.integers(-(1 << 27), 1 << 27, size=sym[::7].size)
+    sym[::11] = offs[idx[::11]] + lens[idx[::11]] - 2          # exactly max_value: escape with raw = 0
+    a = ops.rans_encode(sym, idx, cdf, lens, offs)
+    sr, raw, esc = _np_resolve(sym, idx, cdf, lens, offs)
+    assert ops.rans_encode_resolved(sr, raw, esc) == a
+    assert ops.rans_encode_resolved(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8)) == \
+        ops.rans_encode(np.zeros(0, np.int32), np.zeros(0, np.int32), cdf, lens, offs)
+    bad = esc.copy()
+    bad[0] = 255
+    with pytest.raises(Cra5Error):
+        ops.rans_encode_resolved(sr, raw, bad)
+
+
 def test_decoder_rejects_garbage_without_ub():
     """Random bytes / a non-monotone table decode to an error code or to symbols, never to a crash."""
     rng = np.random.default_rng(9)
