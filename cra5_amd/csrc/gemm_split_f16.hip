@@ -117,24 +117,30 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   // (row = lane/8, physical piece = lane%8), so the XOR swizzle is applied to the per-lane SOURCE
   // address.  A stage is [A rows][W rows] = (BM + BN)/8 one-KB groups, dealt round-robin to the waves.
   // Rows past M / N are clamped to the last row (duplicates, never stored).
-  constexpr int GROUPS = (2 * BM + 2 * BN) / 16;
+  // NPROD == 1 (reduced-precision mode): only the hi plane is staged - 16 rows x 64 B (the first half of
+  // each line) per instruction into 64-byte LDS rows, piece p of row r at p ^ ((r >> 2) & 3): half the
+  // LDS-DMA traffic of the fp32-accurate mode, which is what bounds this mode (1/3 of the MFMAs).
+  constexpr int ROWB = (NPROD == 3) ? 64 : 32;                   // halves per LDS row
+  constexpr int GROUPS = (BM + BN) * ROWB / 512;                 // 1-KB groups per stage
   constexpr int NWAVE = WM * WN;
-  static_assert(GROUPS % NWAVE == 0, "groups must divide evenly over the waves");
-  constexpr int IPW = GROUPS / NWAVE;      // LDS-DMA instructions per wave per k-step
+  constexpr int IPW = (GROUPS + NWAVE - 1) / NWAVE;              // LDS-DMA instructions per wave per k-step
+  static_assert(NPROD == 1 || GROUPS % NWAVE == 0, "groups must divide evenly over the waves");
   const unsigned short *src[IPW];
-  // One instruction = 8 rows x 128 B: a row's [32 hi | 32 lo] chunk is one cache line, requested once
-  // (16 rows x 64 B of one plane per instruction asked for every line twice: -3..6 % on the 192x256 tiles).  LDS rows are
-  // 128 B = 8 pieces [hi 0-3 | lo 4-7]; piece p of row r lives at physical piece p ^ ((r >> 1) & 7):
-  // the 16 rows of a ds_read_b128 lane group then hit 16 distinct 16-byte slots of the 256-B bank row.
+  // NPROD == 3: one instruction = 8 rows x 128 B: a row's [32 hi | 32 lo] chunk is one cache line, requested
+  // once (16 rows x 64 B of one plane per instruction asked for every line twice: -3..6 % on the 192x256
+  // tiles).  LDS rows are 128 B = 8 pieces [hi 0-3 | lo 4-7]; piece p of row r lives at physical piece
+  // p ^ ((r >> 1) & 7): the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte slots.
   {
-    const int lrow = lane >> 3;
+    constexpr int RPG = 512 / ROWB;                              // rows per group: 8 | 16
+    constexpr int LPR = 64 / RPG;                                // lanes per row: 8 | 4
+    const int lrow = lane / LPR;
 #pragma unroll
     for (int q = 0; q < IPW; ++q) {
-      const int gid = wave + q * NWAVE;          // 8 rows of [A rows | W rows]
-      const int grow = gid * 8;
+      const int gid = min(wave + q * NWAVE, GROUPS - 1);         // (NPROD == 1, 192x256: 28 groups on 8 waves)
+      const int grow = gid * RPG;
       const bool isA = grow < BM;
       const int row_ = (isA ? grow : grow - BM) + lrow;
-      const int lpiece = (lane & 7) ^ ((row_ >> 1) & 7);
+      const int lpiece = (NPROD == 3) ? ((lane & 7) ^ ((row_ >> 1) & 7)) : ((lane & 3) ^ ((row_ >> 2) & 3));
       if (isA)
         src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + lpiece * 8;
       else
@@ -150,7 +156,8 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
 #define CRA5_STAGE_LOAD(BUF)                                                                   \
   {                                                                                            \
     _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                          \
-      CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave + q * NWAVE) * 512);                       \
+      if (GROUPS % NWAVE == 0 || wave + q * NWAVE < GROUPS)                                    \
+        CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave + q * NWAVE) * 512);                     \
       src[q] += 64;  /* next k-step: 128 B further along the row */                            \
     }                                                                                          \
   }
@@ -169,15 +176,16 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
 
   // fragment read offsets (halves) inside a stage: row * 64 + (piece ^ sw) * 8, piece = 2*kk + h (hi)
   // or 4 + 2*kk + h (lo); sw = (row >> 1) & 7 = (l31 >> 1) & 7 (sub-tile bases are multiples of 32 rows)
-  const int sw = (l31 >> 1) & 7;
-  const int a_row = (wm * TM * 32 + l31) * 64;
-  const int b_row = BM * 64 + (wn * TN * 32 + l31) * 64;
+  // (NPROD == 1: 64-byte rows, 4 pieces, sw = (row >> 2) & 3)
+  const int sw = (NPROD == 3) ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+  const int a_row = (wm * TM * 32 + l31) * ROWB;
+  const int b_row = BM * ROWB + (wn * TN * 32 + l31) * ROWB;
   int poff[2], poff_lo[2];
   poff[0] = ((0 + h) ^ sw) << 3;
   poff[1] = ((2 + h) ^ sw) << 3;
   poff_lo[0] = ((4 + h) ^ sw) << 3;
   poff_lo[1] = ((6 + h) ^ sw) << 3;
-  constexpr int A_LO = 0, B_LO = 0, SUB = 32 * 64;
+  constexpr int A_LO = 0, B_LO = 0, SUB = 32 * ROWB;
 
   // fragments of one 16-wide k-half (KK = 0 | 1) of stage ST
 #define CRA5_FRAG_READ(AH, AL, BH, BL, ST, KK)                                                 \
