@@ -228,7 +228,9 @@ def main():
                                "traffic_note": "bytes/launch at the L2<->fabric boundary (Infinity-Cache hits "
                                                "included), profiles/r01_traffic.json; algorithmic minimum "
                                                "A + W + C = 55-230 MB/launch",
-                               "peak_note": "dense f16 MFMA peak 2500 TF / %d MFMA(s) per product" % nprod,
+                               "peak_note": "dense f16 MFMA peak 2500 TF / %d MFMA(s) per product; a pure MFMA loop on this "
+                                            "chip sustains 1930-1980 TF at the 1.8-1.9 GHz it clocks under that load "
+                                            "(tools/probes/mfma_peak.hip, DESIGN.md section 9)" % nprod,
                                "mfma_tflops_issued": nprod * ach, "launches": g["launches"],
                                "avg_launch_ms": g["ms"] / g["launches"], "gemm_ms_per_step": g["ms"] * sample / steps,
                                "launches_sampled_every": sample}
