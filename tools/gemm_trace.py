@@ -14,6 +14,9 @@ L.cra5_debug_gemm_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 # (name, M, N, K, gelu, res, split_out)
 SHAPES = [("qkv", 10368, 3072, 1024, False, False, True), ("proj", 10368, 1024, 1024, False, True, False),
           ("fc1", 10368, 4096, 1024, True, False, True), ("fc2", 10368, 1024, 4096, False, True, False)]
+if "--small" in sys.argv:   # a handful of tiles: prologue / epilogue without 256 CUs bursting together
+    SHAPES = [("qkv16", 1024, 3072, 1024, False, False, True), ("fc1_16", 1024, 4096, 1024, True, False, True),
+              ("proj8", 1536, 1024, 1024, False, True, False)]
 for name, M, N, K, gelu, res, so in SHAPES:
     a = torch.randn(M, K, device=dev)
     w = torch.randn(N, K, device=dev) * 0.02
