@@ -350,3 +350,43 @@ def test_tiled_patch_gather_scatter_matches_generic(dev, C):
     assert rmse(back, ref_back * std[:, None, None] + mean[:, None, None]) < 1e-6
     raw = ops.col2im(cols[:, :K], C, 11, 10, 10, 10, 72, 144)
     assert torch.equal(raw.cpu(), ref_back)   # two-term sums: bit-exact
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (2048, 4096, 1024), (10368, 1024, 1024), (648, 360, 360)])
+def test_gemm_hi_only_is_plain_f16(dev, M, N, K):
+    """CRA5_GEMM_HI_ONLY (reduced-precision mode, BASELINE.json configs[4]): the product of the f16-rounded
+    operands with fp32 accumulation - compared against exactly that in float64, and an order of magnitude
+    away from the fp32-accurate result so that the flag is known to take effect."""
+    g = torch.Generator().manual_seed(7 * M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.02
+    b = torch.randn(N, generator=g)
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    sa, sw = ops.split_f16(ad), ops.split_f16(wd, "auto")
+    out = ops.gemm_nt_split(sa, sw, bias=bd, hi_only=True)
+    a16 = a.half().double()
+    w16 = ((w * (1.0 / sw.scale_inv)).half().double()) * sw.scale_inv
+    ref16 = a16 @ w16.t() + b.double()
+    ref32 = a.double() @ w.double().t() + b.double()
+    assert relerr(out, ref16) < 3e-6
+    e = relerr(out, ref32)
+    assert 1e-5 < e < 5e-3, e
+
+
+def test_split_attention_shape_rule(dev):
+    """Windows that are not the whole grid keep a per-block row-offset table: more than
+    ops.MAX_WIN_TOKENS tokens per window is refused by the C ABI (the model then uses the exact-f32
+    kernel, ops.split_attention_ok says so beforehand)."""
+    H, W, C, heads = 64, 64, 64, 1
+    assert ops.split_attention_ok(C, heads, 32, 32, H, W)           # 1024-token windows: fine
+    assert not ops.split_attention_ok(C, heads, 64, 32, H, W)       # 2048-token windows: no
+    assert ops.split_attention_ok(C, heads, 64, 64, H, W)           # the whole grid: fine
+    qkv = ops.split_f16(torch.randn(H * W, 3 * C, device=dev))
+    pad = ops.split_f16(torch.randn(1, 3 * C, device=dev))
+    out = ops.SplitMat.empty(H * W, C, dev, zero=True)
+    with pytest.raises(Exception):
+        ops.window_attention_split(qkv, pad, heads, H, W, 64, 32, out_split=out)
+    ops.window_attention_split(qkv, pad, heads, H, W, 64, 64, out_split=out)
+    ops.window_attention_split(qkv, pad, heads, H, W, 32, 32, out_split=out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.to_float()).all()
