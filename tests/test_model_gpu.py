@@ -385,3 +385,20 @@ def test_gpu_resolved_encoder_same_stream(thin, big, dev):
             net.resolve_on_gpu = keep
         assert a["strings"][0][0] == b["strings"][0][0] and a["strings"][1][0] == b["strings"][1][0]
         assert len(a["strings"][0][0]) > 1000
+
+
+def test_rate_estimate_predicts_stream_size(thin, dev):
+    """forward()'s likelihoods (vaeformer.py:302-333) -> estimated bits (rate_distortion.py:71-74) vs the
+    bytes compress() really writes.  With trained weights the range coder lands within ~1 % of the model
+    entropy; with the synthetic weights used here many residuals fall outside the CDF tables, where the
+    likelihood floor (1e-9 = 30 bits) over-estimates what the escape code spends (bin + a few nibbles), so
+    the streams come out SHORTER than the estimate (measured -18 %): gate loosely, both ways."""
+    from cra5_amd import metrics
+    x = synth.synth_frame(thin.cfg['in_chans'], seed=6).unsqueeze(0).to(dev)
+    out = thin.forward(x)
+    bits = metrics.estimated_bits(out)
+    s = thin.compress(x)["strings"]
+    real = 8.0 * (len(s[0][0]) + len(s[1][0]))
+    print(f"thin: estimated {bits / 8:.0f} bytes, coded {real / 8:.0f} bytes ({100 * (real / bits - 1):+.1f} %)")
+    assert 0.6 * bits <= real <= 1.25 * bits
+    assert metrics.estimated_bpp(out, 721 * 1440) == pytest.approx(bits / (721 * 1440))
