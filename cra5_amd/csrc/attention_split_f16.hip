@@ -61,8 +61,8 @@ __device__ __forceinline__ int token_of(const WinGeom &g, int wr, int wc, int t)
 }
 
 constexpr int HD = 64;
-constexpr int KS = 64;   // K and V LDS row stride (halves): 128 B, unpadded (LDS-DMA writes are linear),
-constexpr int VS = 64;   // bank conflicts avoided by XOR swizzles of the piece index (see the kernel)
+constexpr int KS = 72;   // K LDS row stride (halves): 144 B
+constexpr int VS = 96;   // V LDS row stride (halves): 192 B - see the ds_read_b64_tr_b16 note in the kernel
 constexpr int MAX_WIN_TOKENS = 1536;   // windowed (not whole-grid) launches: L <= this (12 KB offset table)
 
 template <int NW, bool HI, bool GLOBAL>
@@ -71,8 +71,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     const unsigned short *__restrict__ pad_row, float *__restrict__ out, unsigned short *__restrict__ out_s,
     int Kp_out, int C, int heads, WinGeom g, int q_tiles, float scale) {
   constexpr int NT = NW * 64;
-  // [K hi][K lo] : 32 x 128 B ;  [V hi][V lo] : 32 x 128 B (row-major like K, transposed by the READ)
-  constexpr int KPL = 32 * KS;        // K plane stride (halves)
+  constexpr int PIECES = 32 * 16;                 // 16-byte pieces per K (or V) tile
+  constexpr int STG = (PIECES + NT - 1) / NT;
+
+  // [K hi][K lo] : 32 x KS ;  [V hi][V lo] : 32 x VS (row-major like K, transposed by the READ)
+  constexpr int KPL = 32 * KS + 32;   // K plane stride (halves): +64 B so hi/lo planes hit different bank halves
   constexpr int VPL = 32 * VS;        // V plane stride
 #ifndef ATT_LDS_PAD
 #define ATT_LDS_PAD 0
@@ -138,65 +141,75 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   float m_run = -INFINITY, l_run = 0.f;
 
   const int n_tiles = L / 32;
-  // ---- staging by LDS-DMA (global_load_lds_dwordx4): a K or V tile is 2 planes x 32 rows x 128 B =
-  // 8 one-KB instructions (8 rows x 128 B each); the 16 instructions of a (K tile, V tile) pair are
-  // dealt round-robin to the block's waves.  No staging VGPRs, no ds_write pass, and a full tile
-  // iteration between issue and use.  The destination is linear (row = lane/8, physical 16-byte piece
-  // = lane%8), so the bank swizzles are applied to the per-lane SOURCE address:
-  //   K: piece p of row r at p ^ ((r >> 1) & 7)        (conflict-free ds_read_b128 fragments)
-  //   V: piece p of row r at p ^ (((r >> 1) & 1) << 2) (conflict-free ds_read_b64_tr_b16, below)
-  // Source of (row, plane, piece p): the head's 64-d slice of a split row = 2 chunks [32 hi | 32 lo]:
-  // halves offset (p >> 2) * 64 + plane * 32 + (p & 3) * 8.
-  constexpr int NINS = 16;                                  // DMA instructions per (K tile, V tile)
-  constexpr int IPW = (NINS + NW - 1) / NW;                 // per wave
-  const int lrow8 = lane >> 3, lp8 = lane & 7;
-  long src_off[IPW];                                        // halves, inside a split row
-  int src_row[IPW];                                         // row of the tile this lane fetches
-#pragma unroll
-  for (int q = 0; q < IPW; ++q) {
-    const int id = min(wave + q * NW, NINS - 1);            // 0-7: K, 8-15: V; (id >> 2) & 1: plane; id & 3: 8-row group
-    const bool isV = id >= 8;
-    const int plane = (id >> 2) & 1, row = (id & 3) * 8 + lrow8;
-    const int p = isV ? (lp8 ^ (((row >> 1) & 1) << 2)) : (lp8 ^ ((row >> 1) & 7));
-    src_row[q] = row;
-    src_off[q] = (isV ? voff : koff) + (p >> 2) * 64 + plane * 32 + (p & 3) * 8;
-  }
-  // whole-grid launches walk running row pointers (+32 rows per tile and per call: K and V tiles are
-  // requested in order 0, 1, 2, ...); windowed ones look the rows up in the table.
-  const unsigned short *gq[IPW];
-#pragma unroll
-  for (int q = 0; q < IPW; ++q) gq[q] = qkv + (size_t)src_row[q] * ldq + src_off[q];
+  uint4 sk0, sk1 = make_uint4(0u, 0u, 0u, 0u), sv0, sv1 = make_uint4(0u, 0u, 0u, 0u);
+  // K: 16 lanes cover one 256-byte row (coalesced).  V: 32 lanes cover 32 keys at the same
+  // 16-byte column, so that the transposed b16 LDS writes of a half-wave land in 32 consecutive
+  // halves of ONE V^T row (bank-conflict-free).
+  static_assert(STG == 1 || STG == 2, "staging below is written out for one or two 16-byte pieces per thread");
+  constexpr bool TWO = STG == 2;
+  // thread -> (row, piece) of its two K pieces and (row, two pieces) of V; indexes past the tile
+  // (NW = 6: 384 threads x 2 > 512 pieces) are clamped: loaded redundantly, never stored.
+  const int krow0 = min(tid >> 4, 31), krow1 = min((tid + NT) >> 4, 31);
+  const long kcol = koff + (tid & 15) * 8;                                  // halves
+  const long vcol = voff + (tid & 15) * 8;
+  // whole-grid launches walk three running row pointers (+32 rows per tile); windowed ones look
+  // the rows up in the table.
+  const unsigned short *kq0 = qkv + (size_t)krow0 * ldq + kcol;
+  const unsigned short *kq1 = qkv + (size_t)krow1 * ldq + kcol;
+  const unsigned short *vq0 = qkv + (size_t)krow0 * ldq + vcol;
+  const unsigned short *vq1 = qkv + (size_t)krow1 * ldq + vcol;
   const long tile_step = 32 * ldq;
 #define CRA5_ROW(JJ, ROW) \
   reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(qkv) + tab[(JJ)*32 + (ROW)])
-#if defined(__HIP_DEVICE_COMPILE__)
-#define CRA5_GLDS16(SRC, DST) __builtin_amdgcn_global_load_lds(SRC, DST, 16, 0, 0)
-#else
-#define CRA5_GLDS16(SRC, DST) (void)(SRC)
-#endif
-  // request K tile JK into K buffer KBF and / or V tile JV into V buffer VBF (WANT_K / WANT_V: wave-uniform)
-#define CRA5_STAGE(JK, KBF, WANT_K, JV, VBF, WANT_V)                                      \
+#define CRA5_K_LOAD(J)                                                                    \
   {                                                                                       \
-    _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                     \
-      const int id = wave + q * NW;                                                       \
-      if (id < NINS) {                                                                    \
-        const bool isV = id >= 8;                                                         \
-        const bool want = isV ? (WANT_V) : (WANT_K);                                      \
-        if (want) {                                                                       \
-          const unsigned short *sp_;                                                      \
-          if (GLOBAL) {                                                                   \
-            sp_ = gq[q];                                                                  \
-            gq[q] += tile_step;                                                           \
-          } else {                                                                        \
-            sp_ = CRA5_ROW(isV ? (JV) : (JK), src_row[q]) + src_off[q];                   \
-          }                                                                               \
-          unsigned short *dst_ = isV ? Vt + (VBF)*VBUF + (id - 8) * 512 : Ks + (KBF)*KBUF + id * 512; \
-          CRA5_GLDS16(sp_, dst_);                                                         \
-        }                                                                                 \
-      }                                                                                   \
+    if (GLOBAL) {                                                                         \
+      sk0 = *reinterpret_cast<const uint4 *>(kq0);                                        \
+      if (TWO) sk1 = *reinterpret_cast<const uint4 *>(kq1);                               \
+      const long st_ = ((J) < n_tiles - 1) ? tile_step : 0; /* past the end: re-read the last tile */ \
+      kq0 += st_;                                                                         \
+      kq1 += st_;                                                                         \
+    } else {                                                                              \
+      const int jj_ = min((J), n_tiles - 1);                                              \
+      sk0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + kcol);                \
+      if (TWO) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + kcol);       \
     }                                                                                     \
   }
-
+#define CRA5_V_LOAD(J)                                                                    \
+  {                                                                                       \
+    if (GLOBAL) {                                                                         \
+      sv0 = *reinterpret_cast<const uint4 *>(vq0);                                        \
+      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(vq1);                               \
+      const long st_ = ((J) < n_tiles - 1) ? tile_step : 0;                               \
+      vq0 += st_;                                                                         \
+      vq1 += st_;                                                                         \
+    } else {                                                                              \
+      const int jj_ = min((J), n_tiles - 1);                                              \
+      sv0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + vcol);                \
+      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + vcol);       \
+    }                                                                                     \
+  }
+  // piece -> (chunk = piece>>3, plane = (piece>>2)&1, d0 = 32*chunk + 8*(piece&3))
+#define CRA5_K_STORE1(P, BUF)                                                             \
+  {                                                                                       \
+    const int idx = tid + (P)*NT;                                                         \
+    if (idx < PIECES) {                                                                   \
+      const int row = idx >> 4, piece = idx & 15;                                         \
+      const int plane = (piece >> 2) & 1, d0 = 32 * (piece >> 3) + 8 * (piece & 3);       \
+      *reinterpret_cast<uint4 *>(Ks + (BUF)*KBUF + plane * KPL + row * KS + d0) = sk##P;  \
+    }                                                                                     \
+  }
+#define CRA5_K_STORE(BUF) { CRA5_K_STORE1(0, BUF) if (TWO) CRA5_K_STORE1(1, BUF) }
+#define CRA5_V_STORE1(P, BUF)                                                             \
+  {                                                                                       \
+    const int idx = tid + (P)*NT;                                                         \
+    if (idx < PIECES) {                                                                   \
+      const int row = idx >> 4, piece = idx & 15;                                         \
+      const int plane = (piece >> 2) & 1, d0 = 32 * (piece >> 3) + 8 * (piece & 3);       \
+      *reinterpret_cast<uint4 *>(Vt + (BUF)*VBUF + plane * VPL + row * VS + d0) = sv##P;  \
+    }                                                                                     \
+  }
+#define CRA5_V_STORE(BUF) { CRA5_V_STORE1(0, BUF) if (TWO) CRA5_V_STORE1(1, BUF) }
   // S^T tile (32 keys x 32 queries) of the K buffer KB: 12 MFMAs on ATT_S_CHAINS independent
   // accumulators (a dependent 32x32x16 MFMA cannot issue back-to-back), summed at the end.
 #ifndef ATT_S_CHAINS
@@ -209,8 +222,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     _Pragma("unroll") for (int c = 0; c < ATT_S_CHAINS; ++c)                              \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[c][r] = 0.f;                    \
     _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                    \
-      const half8 kh = ATT_KFRAG(k_base + (KB)*KBUF + kp_off[st], qh[3 - st]);            \
-      const half8 kl = ATT_KFRAG(k_base + (KB)*KBUF + KPL + kp_off[st], ql[3 - st]);      \
+      const half8 kh = ATT_KFRAG(k_base + (KB)*KBUF + 16 * st, qh[3 - st]);               \
+      const half8 kl = ATT_KFRAG(k_base + (KB)*KBUF + KPL + 16 * st, ql[3 - st]);         \
       if (!HI) {                                                                          \
         acc_[(3 * st) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], acc_[(3 * st) % ATT_S_CHAINS], 0, 0, 0); \
         acc_[(3 * st + 1) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], acc_[(3 * st + 1) % ATT_S_CHAINS], 0, 0, 0); \
@@ -222,23 +235,15 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     DST = acc_[0];                                                                        \
   }
 
-  // K fragment of k16-step st: logical piece 2 st + h of key row l31, at physical piece ^ ((l31 >> 1) & 7)
-  const unsigned short *k_base = Ks + l31 * KS;                  // + buf*KBUF + plane*KPL + kp_off[st]
-  int kp_off[4];
-#pragma unroll
-  for (int st = 0; st < 4; ++st) kp_off[st] = ((2 * st + h) ^ ((l31 >> 1) & 7)) * 8;
+  const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
   // V^T fragments (A operand: row d = l31, 8 keys per lane) come out of the ROW-MAJOR V image through
   // ds_read_b64_tr_b16: inside each 16-lane group, lane l' receives element (l' & 3) of the 8-byte
   // slots addressed by lanes (l' >> 2) + {0, 4, 8, 12} (probed: tools/probes/tr_probe.hip).  Lane l'
   // therefore ADDRESSES V[kbase + (l' >> 2)][d0 + 4 (l' & 3) ..+3] and RECEIVES V[kbase + 0..3][d0 + l'],
-  // d0 = 32 dt + 16 ((lane >> 4) & 1): four consecutive keys of its own d.  With 128-byte rows, key rows
-  // r and r + 2 share banks: the 16-byte piece index is XORed with ((key >> 1) & 1) << 2, i.e. the two
-  // 32-d halves of rows 2, 3 (mod 4) are swapped, and the four key rows x two d-halves of a 32-lane LDS
-  // cycle fall on 8 disjoint 8-bank ranges.  (key >> 1) & 1 = (l' >> 3) & 1 for every key base used.
-  const int vsk = (lane >> 3) & 1;
-  const unsigned short *v_base0 = Vt + (4 * h + ((lane & 15) >> 2)) * VS + 32 * vsk + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const unsigned short *v_base1 = Vt + (4 * h + ((lane & 15) >> 2)) * VS + 32 * (vsk ^ 1) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  // v_base{dt} + buf*VBUF + plane*VPL + (16*t + 8*a)*VS
+  // d0 = 16 ((lane >> 4) & 1): four consecutive keys of its own d.  Row stride 192 B puts the four
+  // key rows x two d-halves of a 32-lane LDS cycle on 8 disjoint 8-bank ranges (conflict-free).
+  const unsigned short *v_base = Vt + (4 * h + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  // + buf*VBUF + plane*VPL + (16*t + 8*a)*VS + 32*dt
 
   // cross-half max: lanes l and l+32 own the two halves of one query's 32 scores
 #define CRA5_XHALF_MAX(X)                                                                 \
@@ -254,27 +259,27 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     CRA5_XHALF_MAX(fmaxf(m_, n_)) * cexp; /* cexp > 0: max commutes with the scale */      \
   })
 
-  // prologue: K(0), V(0), K(1) resident; S(0) done.  (K tiles are requested in order 0, 1, 2, ... and V
-  // tiles likewise: the running pointers of the whole-grid case rely on it.)
-  CRA5_STAGE(0, 0, true, 0, 0, true);
-  CRA5_STAGE(1, 1, n_tiles > 1, 0, 0, false);
-  __syncthreads();   // (hipcc drains this wave's LDS-DMA - vmcnt - before the barrier)
+  // prologue: K(0), V(0), K(1) resident; K(2), V(1) in flight; S(0) done
+  CRA5_K_LOAD(0);
+  CRA5_V_LOAD(0);
+  CRA5_K_STORE(0);
+  CRA5_V_STORE(0);
+  CRA5_K_LOAD(1);
+  CRA5_K_STORE(1);
+  __syncthreads();
+  CRA5_K_LOAD(2);
+  CRA5_V_LOAD(1);
   f32x16 s_cur;
   CRA5_SCORES(s_cur, 0);
   float mloc = CRA5_TILE_MAX(s_cur);
-  // iteration 0 re-fills K buffer 0 with tile 2: every wave must be done reading tile 0 from it
+  // The end of iteration 0 re-fills K buffer 0 with tile 2: every wave must be done reading tile 0 from
+  // it (a wave a whole iteration ahead of another is unlikely, not impossible).
   __syncthreads();
 
   // Waves past the end of the window (q_tok < 0 for all lanes) run the same instruction stream
   // on the pad row and store nothing: one code path, no divergent barriers.
   for (int j = 0; j < n_tiles; ++j) {
     const int kb = (j + 1) & 1, vb = j & 1;
-#ifndef ATT_SKIP_STAGE
-    // K(j+2) -> the buffer tile j's scores came from, V(j+1) -> the buffer tile j-1's PV read: both were
-    // last read before the barrier that ended the previous iteration; they land during this one and
-    // become visible at its barrier.
-    CRA5_STAGE(j + 2, j & 1, j + 2 < n_tiles, j + 1, (j + 1) & 1, j + 1 < n_tiles);
-#endif
     // tile j's running max is known before its softmax starts (mloc was reduced in the shadow of
     // the previous tile's PV MFMAs), so the rare O rescale sits at the top and everything below
     // is ONE basic block the scheduler can interleave.
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
       half8 vh[2], vl[2];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const unsigned short *vp = (dt ? v_base1 : v_base0) + vb * VBUF + 16 * t * VS;
+        const unsigned short *vp = v_base + vb * VBUF + 16 * t * VS + 32 * dt;
         const half4 a0 = CRA5_TR_READ(vp);
         const half4 a1 = CRA5_TR_READ(vp + 8 * VS);
         const half4 b0 = CRA5_TR_READ(vp + VPL);
@@ -351,6 +356,15 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one score MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, ATT_VALU_PER_MFMA, 0);  // softmax VALU in its shadow
     }
+#endif
+    // K(j+2) -> the buffer tile j's scores came from (last read before the previous barrier),
+    // V(j+1) -> the other V buffer (past the end: stale data into buffers nobody reads);
+    // then start fetching K(j+3), V(j+2).
+#ifndef ATT_SKIP_STAGE
+    CRA5_K_STORE(j & 1);
+    CRA5_V_STORE((j + 1) & 1);
+    CRA5_K_LOAD(j + 3);
+    CRA5_V_LOAD(j + 2);
 #endif
 #ifndef ATT_SKIP_BARRIER
     __syncthreads();
