@@ -287,6 +287,7 @@ class VAEformer(nn.Module):
         self._gpu_sem = None
         # the ~1 ms h_s phase between the two host phases of a decode does not queue for a slot
         self.light_bypass = os.environ.get("CRA5_LIGHT_BYPASS", "1") != "0"
+        self.light_priority = os.environ.get("CRA5_LIGHT_PRIORITY", "1") != "0"
         self._tls = threading.local()  # per-thread workspaces: one frame pipeline per thread/stream
         self.eval()
 
@@ -614,8 +615,20 @@ class VAEformer(nn.Module):
                 sem[1].acquire()
             t1 = time.perf_counter() if log is not None else 0.0
             try:
-                yield
-                torch.cuda.current_stream().synchronize()
+                if light and self.light_priority:
+                    # the ~1 ms h_s phase sits between a frame's two host phases: on a high-priority
+                    # HIP stream its small kernels are scheduled ahead of the other frames' queued
+                    # blocks instead of behind them (the previous phase of this frame ended with a
+                    # stream sync, so switching streams needs no event)
+                    hp = getattr(self._tls, "hp_stream", None)
+                    if hp is None:
+                        hp = self._tls.hp_stream = torch.cuda.Stream(device=self.device, priority=-1)
+                    with torch.cuda.stream(hp):
+                        yield
+                        hp.synchronize()
+                else:
+                    yield
+                    torch.cuda.current_stream().synchronize()
             finally:
                 if sem is not None:
                     sem[1].release()
