@@ -169,13 +169,19 @@ def main():
     t0 = time.perf_counter()
     # EXACTLY K steps = K full round trips; up to `inflight` frames overlap, all K complete
     # (streams synchronised, x_hat materialised) before the clock stops.
-    results = pipe.roundtrip([frames[i % 2] for i in range(args.steps)])
+    # Only the byte streams and a finiteness probe of every reconstruction are kept: x_hat is 1.11 GB per
+    # frame (600 retained frames would not fit 288 GB); it is fully produced on the device either way.
+    def round_trip(x):
+        out = net.compress(x)
+        x_hat = net.decompress(out["strings"], out["z_shape"])["x_hat"]
+        return out, torch.isfinite(x_hat[0, 0, ::97, ::97]).all()
+    results = pipe.map(round_trip, [frames[i % 2] for i in range(args.steps)])
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
     rows = [D.frame_stats(rank * args.steps + i, out["strings"]) for i, (out, _) in enumerate(results)]
-    assert all(torch.isfinite(x_hat[0, 0, ::97, ::97]).all() for _, x_hat in results)
+    assert all(bool(ok) for _, ok in results)
     elapsed = D.max_over_ranks(elapsed, dev)
     stats = D.gather_stats(rows, dev)  # RCCL all-gather of per-frame bitstream stats
 
