@@ -91,7 +91,7 @@ def cpu_baseline(quality, n_threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--quality", type=int, default=268)
     ap.add_argument("--precision", choices=("fp32", "f16"), default=os.environ.get("CRA5_PRECISION", "fp32"),
