@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   float m_run = -INFINITY, l_run = 0.f;
 
   const int n_tiles = L / 32;
-  uint4 sk0, sk1 = make_uint4(0u, 0u, 0u, 0u), sv0, sv1 = make_uint4(0u, 0u, 0u, 0u);
+  uint4 sk0 = make_uint4(0u, 0u, 0u, 0u), sk1 = sk0, sv0 = sk0, sv1 = sk0;
   // K: 16 lanes cover one 256-byte row (coalesced).  V: 32 lanes cover 32 keys at the same
   // 16-byte column, so that the transposed b16 LDS writes of a half-wave land in 32 consecutive
   // halves of ONE V^T row (bank-conflict-free).
@@ -161,32 +161,36 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   const long tile_step = 32 * ldq;
 #define CRA5_ROW(JJ, ROW) \
   reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(qkv) + tab[(JJ)*32 + (ROW)])
+  // (waves whose pieces fall past the 512 of a tile - 4 of 12, or the second piece of 4 of 6 - skip the
+  // loads and their address arithmetic altogether: the conditions are wave-uniform)
+  const bool stage0 = (NT <= PIECES) || (tid < PIECES);
+  const bool stage1 = TWO && (tid + NT < PIECES);
 #define CRA5_K_LOAD(J)                                                                    \
-  {                                                                                       \
+  if (stage0) {                                                                           \
     if (GLOBAL) {                                                                         \
       sk0 = *reinterpret_cast<const uint4 *>(kq0);                                        \
-      if (TWO) sk1 = *reinterpret_cast<const uint4 *>(kq1);                               \
+      if (stage1) sk1 = *reinterpret_cast<const uint4 *>(kq1);                            \
       const long st_ = ((J) < n_tiles - 1) ? tile_step : 0; /* past the end: re-read the last tile */ \
       kq0 += st_;                                                                         \
       kq1 += st_;                                                                         \
     } else {                                                                              \
       const int jj_ = min((J), n_tiles - 1);                                              \
       sk0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + kcol);                \
-      if (TWO) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + kcol);       \
+      if (stage1) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + kcol);    \
     }                                                                                     \
   }
 #define CRA5_V_LOAD(J)                                                                    \
-  {                                                                                       \
+  if (stage0) {                                                                           \
     if (GLOBAL) {                                                                         \
       sv0 = *reinterpret_cast<const uint4 *>(vq0);                                        \
-      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(vq1);                               \
+      if (stage1) sv1 = *reinterpret_cast<const uint4 *>(vq1);                            \
       const long st_ = ((J) < n_tiles - 1) ? tile_step : 0;                               \
       vq0 += st_;                                                                         \
       vq1 += st_;                                                                         \
     } else {                                                                              \
       const int jj_ = min((J), n_tiles - 1);                                              \
       sv0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + vcol);                \
-      if (TWO) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + vcol);       \
+      if (stage1) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + vcol);    \
     }                                                                                     \
   }
   // piece -> (chunk = piece>>3, plane = (piece>>2)&1, d0 = 32*chunk + 8*(piece&3))
