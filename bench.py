@@ -27,6 +27,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP runtime knobs, read when the runtime initialises (so before torch is imported): one hardware
+# queue per frame stream instead of 4 shared ones, kernel arguments in device memory.  Worth ~0.5 %.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import torch  # noqa: E402
 
