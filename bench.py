@@ -277,27 +277,24 @@ def main():
 
     if timer is not None:
         timed = roofline_from(timer.summary(), args.steps, args.timer_sample)
-        if args.exclusive or args.inflight == 1:
-            result.update(timed)
-            result["roofline"]["measured_over"] = "the timed region (exclusive GPU phases: every launch runs alone)"
-        else:
-            # Kernels of concurrent frames overlapped in the timed region, so start->stop of one
-            # launch also contains other frames' kernels.  Keep those raw numbers, and time the
-            # SAME kernels un-overlapped in a short extra pass (outside the timed region).
-            result["roofline_timed_region"] = timed.get("roofline")
-            result["attention_timed_region"] = timed.get("attention")
-            net.gpu_exclusive = True
-            ops.TIMER = t2 = ops.KernelTimer()
-            pipe.roundtrip([frames[i % 2] for i in range(args.roofline_steps)])
-            torch.cuda.synchronize()
-            ops.TIMER = None
-            result.update(roofline_from(t2.summary(), args.roofline_steps))
-            if "roofline" in result:
-                result["roofline"]["measured_over"] = (
-                    f"a separate un-overlapped pass of {args.roofline_steps} frames run right after the timed "
-                    "region (HIP events on the launch stream, exclusive GPU phases); `roofline_timed_region` "
-                    "holds the same measurement taken inside the timed region, where launches of concurrent "
-                    "frames overlap and per-launch durations are inflated")
+        # In the timed region only every n-th launch is bracketed (and, in the default mode, launches of
+        # concurrent frames overlap, so start->stop of one launch also contains other frames' kernels).
+        # Keep those numbers, and time EVERY launch of the same kernels un-overlapped in a short extra
+        # pass outside the timed region.
+        result["roofline_timed_region"] = timed.get("roofline")
+        result["attention_timed_region"] = timed.get("attention")
+        net.gpu_exclusive = True
+        ops.TIMER = t2 = ops.KernelTimer()
+        pipe.roundtrip([frames[i % 2] for i in range(max(1, args.roofline_steps))])
+        torch.cuda.synchronize()
+        ops.TIMER = None
+        result.update(roofline_from(t2.summary(), max(1, args.roofline_steps)))
+        if "roofline" in result:
+            result["roofline"]["measured_over"] = (
+                f"a separate un-overlapped pass of {max(1, args.roofline_steps)} frames run right after the timed "
+                "region (HIP events around every launch, on the launch stream, exclusive GPU phases); "
+                "`roofline_timed_region` holds the sampled measurement taken inside the timed region, where "
+                "launches of concurrent frames overlap and per-launch durations are inflated")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(args.quality, os.cpu_count() or 1)
