@@ -63,29 +63,56 @@ class cra5_api:
         raise RuntimeError("ERA5 download needs network access + the CDS API (out of scope offline); "
                            "place the NetCDF files under {local_root}/ERA5/{yyyy}/ or pass data=")
 
+    @staticmethod
+    def _open_nc(path):
+        """-> (get(name) -> ndarray with packing (scale_factor / add_offset / _FillValue) undone, close()).
+        xarray + netCDF4 when importable (what the reference uses, cra5_api.py:203-208); otherwise
+        scipy.io.netcdf_file, which reads the NetCDF-3 classic / 64-bit-offset files the CDS legacy
+        API delivers (NetCDF-4 / HDF5 files need xarray)."""
+        try:
+            import xarray as xr
+        except ImportError:
+            xr = None
+        if xr is not None:
+            ds = xr.open_dataset(path, engine='netcdf4')
+            return (lambda name: ds[name].data), ds.close
+        from scipy.io import netcdf_file
+        with open(path, "rb") as f:
+            magic = f.read(4)
+        if magic[:3] != b"CDF":
+            raise RuntimeError(f"{path}: not a NetCDF-3 file (magic {magic!r}); reading NetCDF-4 needs xarray + "
+                               "netCDF4, which this image lacks - pass data= instead")
+        nc = netcdf_file(path, "r", mmap=False, maskandscale=True)
+
+        def get(name):
+            a = np.ma.filled(nc.variables[name][:], np.nan)
+            return np.asarray(a, dtype=np.float32 if a.dtype.kind == "f" else a.dtype)
+        return get, nc.close
+
     def read_data_from_nc(self, time_stamp):
         """cra5_api.py:195-226: (268, 721, 1440) float32, pressure vars x levels then singles,
         tp scaled by 1000."""
-        try:
-            import xarray as xr
-        except ImportError as e:  # pragma: no cover
-            raise RuntimeError("reading ERA5 NetCDF needs xarray + netCDF4; pass data= instead") from e
         one_step = []
         pressure_file = f'{self.local_root}/ERA5/{time_stamp[:4]}/{time_stamp}_pressure.nc'
         single_file = f'{self.local_root}/ERA5/{time_stamp[:4]}/{time_stamp}_single.nc'
-        pressure_data = xr.open_dataset(pressure_file, engine='netcdf4')
-        single_data = xr.open_dataset(single_file, engine='netcdf4')
-        for vname in self.vnames['pressure']:
-            D = pressure_data[vname].data
-            pha = list(pressure_data.level.data)
-            for level in [pha.index(v) for v in self.pressure_level if v in pha]:
-                one_step.append(D[0][level][None])
-        for vname in self.vnames['single']:
-            D = single_data[vname].data
-            if vname == 'tp':
-                D = D * 1000
-            one_step.append(D)
-        return np.concatenate(one_step, 0)
+        pget, pclose = self._open_nc(pressure_file)
+        sget, sclose = self._open_nc(single_file)
+        try:
+            pha = [float(v) for v in pget('level')]
+            level_mapping = [pha.index(v) for v in self.pressure_level if v in pha]
+            for vname in self.vnames['pressure']:
+                D = pget(vname)
+                for level in level_mapping:
+                    one_step.append(D[0][level][None])
+            for vname in self.vnames['single']:
+                D = sget(vname)
+                if vname == 'tp':
+                    D = D * 1000
+                one_step.append(D)
+        finally:
+            pclose()
+            sclose()
+        return np.concatenate(one_step, 0).astype(np.float32, copy=False)
 
     def _frame(self, time_stamp, data):
         if data is None:

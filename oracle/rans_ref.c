@@ -77,6 +77,11 @@ int oracle_rans_encode(const int32_t *symbols, const int32_t *indexes, size_t n,
     else if (value >= max_value) { raw_val = (uint32_t)(2 * (value - max_value)); value = max_value; }
     PUSH(cdf[value], cdf[value + 1] - cdf[value], 0);
     if (value == max_value) {
+      /* raw_val >= 2^28 needs 8 nibbles: the reference's loop below then evaluates `raw_val >> 32`
+       * on a uint32_t (undefined; x86 masks the count to 0 and the loop never ends,
+       * rans_interface.cpp:152-154).  Outside the reference's defined domain: refuse instead of
+       * reproducing the hang (|symbol - offset| < 2^27 is always safe). */
+      if (raw_val >> 28) { free(syms); return -3; }
       int32_t n_bypass = 0;
       while ((raw_val >> (n_bypass * BYPASS_PRECISION)) != 0) ++n_bypass;
       int32_t val = n_bypass;

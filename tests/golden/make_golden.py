@@ -13,6 +13,13 @@ dumps small input/output fixtures (data only) next to this script:
   thin_e2e.npz          full-spatial thin model: every stage of encode / latent side /
                         decode, sub-sampled, + rANS strings
   full268.npz           (--stage full; ~3 min, ~18 GB RAM) the real 268 architecture
+  full159.npz           (--stage full159) BASELINE configs[1]: the same architecture with 159
+                        variables (reference `VAEformer(0, ddconfig=... in_chans=159 ...)`,
+                        the ddconfig route of vaeformer.py:78-143; `VAEformer(159)` itself
+                        crashes in the reference), encode_latent + decode_latent
+  era5_stats_ref.npz    (--stage stats) the reference's own 268-long mean / std vectors
+                        (cra5_api.get_mean_std, cra5_api.py:243-261) and channel -> vname map
+                        (:228-241), computed by the reference's code on its own JSONs/config
   thin_fp64.npz / full268_fp64.npz  (--stage thin64 / full64) the reference run in float64:
                         calibration of the fp32 noise floor of the reference itself
 
@@ -264,6 +271,92 @@ def stage_full():
     print("full done")
 
 
+def build_159():
+    """The 268 architecture with 159 variables through the reference's ddconfig route
+    (model_version != 268): same kwargs as the hard-wired 268 config, in_chans = out_chans = 159."""
+    dd_kw = dict(z_dim=None, learnable_pos=True, window=True, window_size=[(24, 24), (12, 48), (48, 12)],
+                 interval=4, drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                 test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=True, img_size=(721, 1440))
+    pr_kw = dict(z_dim=256, embed_dim=360, depth=8, num_heads=5, interval=1, learnable_pos=True, window=False,
+                 drop_path_rate=0., round_padding=True, pad_attn_mask=True,
+                 test_pos_mode='learnable_simple_interpolate', lms_checkpoint_train=False, img_size=(72, 144))
+    return VAEformer(0, embed_dim=256, z_channels=256, y_channels=1024, sample_posterior=False,
+                     frozen_encoder=False, lower_dim=True,
+                     ddconfig=dict(arch='vit_large', pretrained_model='', patch_size=(11, 10), patch_stride=(10, 10),
+                                   in_chans=159, out_chans=159, kwargs=dd_kw),
+                     priorconfig=dict(pretrained_model='', patch_size=(4, 4), in_chans=256, out_chans=256,
+                                      kwargs=pr_kw)).eval()
+
+
+def stage_full159():
+    """BASELINE configs[1]: x ~ N(0,1) seed 1, encode_to_latent + latent_to_reconstruction."""
+    net = build_159()
+    shapes = load_synth(net, seed=3)
+    x = synth.synth_frame(159, seed=1).unsqueeze(0)
+    o = {}
+    t0 = time.time()
+    y, _, _ = net.encode_latent(x, type='float')
+    print("159 g_a", time.time() - t0)
+    o["y_sub"], o["y_stats"] = sub(y, 499), stats(y)
+    t0 = time.time()
+    x_hat = net.decode_latent(synth_yhat(256, 5))
+    print("159 g_s", time.time() - t0)
+    o["xhat_sub"], o["xhat_stats"] = sub(x_hat, 99991), stats(x_hat)
+    o["xhat_row10_c0"] = x_hat[0, 0, 10].numpy()
+    o["xhat_row720_c158"] = x_hat[0, 158, 720].numpy()
+    # end to end on the reference's own quantised latent: x_hat(y_hat(x)) sub-sampled
+    _, y_hat, _ = net.encode_latent(x, type='quantized')
+    o["y_hat_sub"] = sub(y_hat, 499)
+    np.savez_compressed(os.path.join(HERE, "full159.npz"), **o)
+    sk = json.load(open(os.path.join(HERE, "state_keys.json")))
+    sk["v159"] = {k: list(v) for k, v in shapes.items()}
+    json.dump(sk, open(os.path.join(HERE, "state_keys.json"), "w"))
+    print("full159 done")
+
+
+def stage_stats():
+    """The reference's cra5_api.get_mean_std / channel_vname_mapping run on the reference's own
+    config + JSON files (the methods only read self.cfg / self.level_mapping, so they are called
+    on a bare object: the constructor needs the network)."""
+    import importlib
+    import types
+
+    class Config(dict):
+        """Import stand-in for cra5.utils.config.Config (needs yapf / addict, absent here): the
+        reference's config file is plain Python, exec'd into an attribute dict."""
+        __getattr__ = dict.__getitem__
+
+        @staticmethod
+        def fromfile(path):
+            ns = {}
+            exec(compile(open(path).read(), path, "exec"), ns)  # noqa: S102
+            return Config({k: v for k, v in ns.items() if not k.startswith("__")})
+
+    stubs = {"cra5.utils.config": dict(Config=Config), "cra5.api.era5_downloader": dict(era5_downloader=object)}
+    for name in ("matplotlib", "matplotlib.pyplot", "xarray", "cdsapi"):
+        try:
+            importlib.import_module(name)
+        except Exception:  # noqa: BLE001
+            stubs[name] = {}
+    for name, attrs in stubs.items():
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    import cra5.api  # noqa: F401
+    ref_api_mod = sys.modules['cra5.api.cra5_api']
+    api = object.__new__(ref_api_mod.cra5_api)
+    api.cfg = Config.fromfile(os.path.join(os.path.dirname(ref_api_mod.__file__), "cra5_268v_config.py"))
+    api.level_mapping = [api.cfg.total_levels.index(v) for v in api.cfg.pressure_level if v in api.cfg.total_levels]
+    mean, std = api.get_mean_std()
+    c2v, v2c = api.channel_vname_mapping()
+    assert mean.shape == (268,) and len(c2v) == 268
+    np.savez_compressed(os.path.join(HERE, "era5_stats_ref.npz"), mean=mean, std=std,
+                        vnames=np.array([c2v[i] for i in range(268)]),
+                        level_mapping=np.array(api.level_mapping, dtype=np.int64))
+    print("stats done")
+
+
 def stage_fp64(which="full"):
     """The reference in float64 on the same weights / inputs: calibrates the fp32 noise floor
     (how far the reference's OWN fp32 path is from exact arithmetic).  ~6 min, ~40 GB for
@@ -298,5 +391,5 @@ if __name__ == "__main__":
     ap.add_argument("--stage", nargs="+", default=["small", "thin"])
     a = ap.parse_args()
     for s in a.stage:
-        dict(small=stage_small, thin=stage_thin, full=stage_full, thin64=lambda: stage_fp64("thin"),
-             full64=lambda: stage_fp64("full"))[s]()
+        dict(small=stage_small, thin=stage_thin, full=stage_full, full159=stage_full159, stats=stage_stats,
+             thin64=lambda: stage_fp64("thin"), full64=lambda: stage_fp64("full"))[s]()

@@ -134,6 +134,81 @@ def test_api_host_plumbing(tmp_path):
         api.encode_to_latent("2024-06-01T00:00:00", data=torch.zeros(268, 721, 1440))
 
 
+def test_api_stats_equal_reference_dump(tmp_path, golden_dir):
+    """mean / std vectors and channel names == what the reference's own get_mean_std /
+    channel_vname_mapping return (tests/golden/make_golden.py --stage stats)."""
+    import numpy as np
+    from cra5_amd.api import cra5_api
+    g = np.load(f"{golden_dir}/era5_stats_ref.npz")
+    api = cra5_api(local_root=str(tmp_path), device="cpu", weights=VAEformer(0, **synth.thin_model_kwargs()))
+    mean, std = api.get_mean_std()
+    assert mean.dtype == np.float32 and np.array_equal(mean, g["mean"]) and np.array_equal(std, g["std"])
+    assert [api.channels_to_vname[i] for i in range(268)] == list(g["vnames"])
+    assert api.level_mapping == list(g["level_mapping"])
+    assert all(api.vname_to_channels[n] == i for i, n in enumerate(g["vnames"]))
+
+
+def test_netcdf_ingest_channel_order(tmp_path):
+    """read_data_from_nc (cra5_api.py:195-226) on tiny synthetic NetCDF-3 files: pressure variables x
+    levels in cfg.pressure_level order whatever the file's level order, packed (scale/offset) variables
+    unpacked, then the singles with tp x 1000."""
+    import numpy as np
+    from scipy.io import netcdf_file
+    from cra5_amd.api import cra5_api
+    api = cra5_api(local_root=str(tmp_path), device="cpu", weights=VAEformer(0, **synth.thin_model_kwargs()))
+    ts = "2024-06-01T00:00:00"
+    d = tmp_path / "ERA5" / "2024"
+    d.mkdir(parents=True)
+    H, W = 3, 4
+    rng = np.random.default_rng(5)
+    levels = np.array(api.total_levels, dtype=np.float32)[::-1].copy()   # file order: 1 ... 1000 hPa
+    truth = {}
+    f = netcdf_file(str(d / f"{ts}_pressure.nc"), "w")
+    for name, n in (("time", 1), ("level", 37), ("latitude", H), ("longitude", W)):
+        f.createDimension(name, n)
+    lv = f.createVariable("level", "f4", ("level",))
+    lv[:] = levels
+    for k, v in enumerate(api.vnames["pressure"]):
+        a = rng.standard_normal((1, 37, H, W)).astype(np.float32) * (k + 1)
+        var = f.createVariable(v, "i2" if v == "q" else "f4", ("time", "level", "latitude", "longitude"))
+        if v == "q":   # packed like CDS legacy files
+            sf, ao = np.float32(1e-3), np.float32(0.5)
+            packed = np.rint((a - ao) / sf).astype(np.int16)
+            var[:] = packed
+            var.scale_factor, var.add_offset = sf, ao
+            a = packed.astype(np.float64) * sf + ao
+        else:
+            var[:] = a
+        truth[v] = np.asarray(a, dtype=np.float32)
+    f.close()
+    f = netcdf_file(str(d / f"{ts}_single.nc"), "w")
+    for name, n in (("time", 1), ("latitude", H), ("longitude", W)):
+        f.createDimension(name, n)
+    for v in api.vnames["single"]:
+        a = rng.standard_normal((1, H, W)).astype(np.float32)
+        f.createVariable(v, "f4", ("time", "latitude", "longitude"))[:] = a
+        truth[v] = a
+    f.close()
+    x = api.read_data_from_nc(ts)
+    assert x.shape == (268, H, W) and x.dtype == np.float32
+    for ch in range(268):
+        name = api.channels_to_vname[ch]
+        if "_" in name and name.split("_")[0] in api.vnames["pressure"]:
+            v, lev = name.split("_")
+            want = truth[v][0, list(levels).index(float(lev))]
+        else:
+            want = truth[name][0] * (1000 if name == "tp" else 1)
+        assert np.allclose(x[ch], want, rtol=1e-6, atol=1e-7), name
+    # a NetCDF-4 (HDF5) file is refused with a clear message when xarray is absent
+    try:
+        import xarray  # noqa: F401
+    except ImportError:
+        (d / "2024-06-01T01:00:00_pressure.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+        (d / "2024-06-01T01:00:00_single.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+        with pytest.raises(RuntimeError, match="NetCDF-4"):
+            api.read_data_from_nc("2024-06-01T01:00:00")
+
+
 def test_install_dropin():
     import cra5_amd
     cra5_amd.install_dropin()

@@ -125,21 +125,49 @@ def test_thin_roundtrip_and_bitstreams(thin, thin_side, dev, golden_dir, tmp_pat
     # (4) versus the stream the REFERENCE python produced (with the oracle coder): identical
     #     when the integer inputs are identical
     same_ints = (torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1)))
-    if same_ints:
-        assert z_str == g["z_string"].tobytes()
     sha = hashlib.sha256(y_str).digest()
     hist = np.bincount((s["y_sym"].cpu().numpy().reshape(-1) + 256).clip(0, 512), minlength=513)
     idx_hist = np.bincount(s["idx"].cpu().numpy().reshape(-1), minlength=64)
-    if np.array_equal(hist, g["sym_hist"]) and np.array_equal(idx_hist, g["idx_hist"]):
+    same_y = np.array_equal(hist, g["sym_hist"]) and np.array_equal(idx_hist, g["idx_hist"])
+    print(f"thin streams vs reference-python streams: z integers identical {same_ints}, y integers identical {same_y}")
+    if same_ints:
+        assert z_str == g["z_string"].tobytes()
+    if same_y:
         assert sha == g["y_string_sha256"].tobytes()
+        assert y_str == g["y_string"].tobytes()
     else:
         assert abs(len(y_str) - int(g["y_string_len"][0])) <= 64
+    ints_equal = same_ints and same_y
     # (5) full decode: x_hat from the stream == decode_latent(y_hat) exactly (deterministic kernels)
     xa = thin.decompress(out["strings"], out["z_shape"])["x_hat"]
     xb = thin.decode_latent(y_hat)
     assert torch.equal(xa, xb)
     # and x -> bin -> x_hat reconstructs x_hat(oracle) within the symbol-flip bound
     assert torch.isfinite(xa).all()
+    if not ints_equal:
+        # round 1 measured NO flip on this frame (seed 2 / synth seed 7): say so loudly instead of passing
+        pytest.xfail("integer side differs from the reference run (rounding flip): byte equality with the "
+                     "reference-python stream (4) was not exercised on this build")
+
+
+def test_thin_decodes_the_reference_stream(thin, thin_side, dev, golden_dir):
+    """Cross-implementation decode: the `.bin` strings the REFERENCE's compress() wrote (thin_e2e.npz,
+    through the oracle coder) fed to the product's decompress().  Needs bit-identical CDF indexes from
+    the product's h_s; a single flipped index desynchronises the rest of the stream,
+    so the integer side is checked first and a mismatch is reported as such, never skipped silently."""
+    g = np.load(f"{golden_dir}/thin_e2e.npz")
+    _, y, s = thin_side
+    z_same = torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1))
+    idx_same = np.array_equal(np.bincount(s["idx"].cpu().numpy().reshape(-1), minlength=64), g["idx_hist"])
+    if not (z_same and idx_same):
+        pytest.xfail("product and reference disagree on a z symbol / CDF index for this frame (rounding flip): "
+                     "the reference's stream cannot be decoded by this build - see DESIGN section 11")
+    y_hat = thin.decompress([[g["y_string"].tobytes()], [g["z_string"].tobytes()]], (18, 36), return_format='latent')
+    d = (sub(y_hat, 37) - torch.from_numpy(g["y_hat_sub"])).abs()
+    assert float(d.max()) <= 1e-4, float(d.max())     # same symbols + means within fp32 noise
+    sym_hist = np.bincount((torch.round(y_hat[0].reshape(-1) - s["means"].reshape(-1)).int().cpu().numpy() + 256)
+                           .clip(0, 512), minlength=513)
+    assert np.array_equal(sym_hist, g["sym_hist"])
 
 
 def test_thin_vs_cpu_oracle(thin, thin_side, dev):
@@ -275,6 +303,24 @@ def test_full268_vs_reference_golden(big, dev, golden_dir):
     # x -> bin -> y_hat round trip at full size
     out = big.compress_from_latent(y)
     assert abs(len(out["strings"][0][0]) - int(g["y_string_len"][0])) <= 256
+    # full-size, escape-heavy streams byte-for-byte against the oracle coder on the same integers
+    # (entropy_models.py:263-271 -> rans_interface.cpp:108-200)
+    eb, gc = big.entropy_bottleneck, big.gaussian_conditional
+    o_y = cbind.rans_encode(s["y_sym"].cpu().numpy().reshape(-1), s["idx"].cpu().numpy().reshape(-1),
+                            gc._quantized_cdf.cpu().numpy(), gc._cdf_length.cpu().numpy(), gc._offset.cpu().numpy())
+    assert out["strings"][0][0] == o_y
+    z_idx = eb._build_indexes((1,) + tuple(s["z_sym"].shape)).reshape(-1)
+    o_z = cbind.rans_encode(s["z_sym"].cpu().numpy().reshape(-1), z_idx, eb._quantized_cdf.cpu().numpy(),
+                            eb._cdf_length.cpu().numpy(), eb._offset.cpu().numpy())
+    assert out["strings"][1][0] == o_z
+    # ... and the oracle DECODER reads the product's stream back to the same symbols
+    back = cbind.rans_decode(out["strings"][0][0], s["idx"].cpu().numpy().reshape(-1), gc._quantized_cdf.cpu().numpy(),
+                             gc._cdf_length.cpu().numpy(), gc._offset.cpu().numpy())
+    assert torch.equal(back.reshape(-1), s["y_sym"].cpu().reshape(-1))
+    if z_hist_l1 == 0 and z_flips == 0 and np.array_equal(hist, g["sym_hist"]) and np.array_equal(idx_hist, g["idx_hist"]):
+        # identical integers to the reference run: the stream the reference's python wrote is ours
+        assert hashlib.sha256(out["strings"][0][0]).digest() == g["y_string_sha256"].tobytes()
+        assert out["strings"][1][0] == g["z_string"].tobytes()
     y_hat = big.decompress(out["strings"], out["z_shape"], return_format='latent')
     assert torch.equal(y_hat[0].reshape(-1), s["y_hat"].reshape(-1))
     # decoder, identical y_hat
@@ -286,16 +332,66 @@ def test_full268_vs_reference_golden(big, dev, golden_dir):
     assert rmse(x_hat[0, 0, 720].cpu(), g["xhat_row720_c0"]) <= 1e-5
 
 
-def test_quality_159_runs(dev):
-    """config[1] of BASELINE.json: 159-variable variant, encode_to_latent + reconstruction."""
+def test_quality_159_vs_reference_golden(dev, golden_dir):
+    """configs[1] of BASELINE.json: the 159-variable variant, encode_to_latent + latent_to_reconstruction,
+    against the reference's own `VAEformer(0, ddconfig=... in_chans=159 ...)` on the same synthetic
+    weights (tests/golden/make_golden.py --stage full159)."""
+    g = np.load(f"{golden_dir}/full159.npz")
     net = vaeformer_pretrained(quality=159, pretrained=False)
-    synth.load_synthetic(net, seed=3, update=False)
+    synth.load_synthetic(net, seed=3)
     net = net.to(dev)
     x = synth.synth_frame(159, seed=1).unsqueeze(0).to(dev)
     y = net.encode_latent(x, type='float')[0]
     assert y.shape == (1, 256, 72, 144) and torch.isfinite(y).all()
-    x_hat = net.decode_latent(y)
+    e_y = rmse(sub(y, 499), g["y_sub"])
+    assert abs(float(y.double().sum()) - g["y_stats"][0]) <= 1e-5 * y.numel()
+    x_hat = net.decode_latent(synth_yhat(256, 5).to(dev))
     assert x_hat.shape == (1, 159, 721, 1440) and torch.isfinite(x_hat).all()
+    e_x = rmse(sub(x_hat, 99991), g["xhat_sub"])
+    print(f"159: y rmse {e_y:.3e}, x_hat rmse {e_x:.3e} (given identical y_hat)")
+    assert e_y <= 1e-5 and e_x <= 1e-5
+    assert rmse(x_hat[0, 0, 10].cpu(), g["xhat_row10_c0"]) <= 1e-5
+    assert rmse(x_hat[0, 158, 720].cpu(), g["xhat_row720_c158"]) <= 1e-5
+    # quantised latent: rounding flips are counted, not hidden
+    y_hat = net.encode_latent(x, type='quantized')[1]
+    d = (sub(y_hat, 499) - torch.from_numpy(g["y_hat_sub"])).abs()
+    flips = int((d > 0.5).sum())
+    print(f"159: y_hat flips {flips}/{d.numel()}")
+    assert flips <= 2 and float(d[d <= 0.5].max()) <= 5e-3
+
+
+def test_api_268_channels_real_stats(big, dev, golden_dir, tmp_path):
+    """cra5_api on the 268 model with the reference's real 268-long mean / std vectors
+    (era5_stats_ref.npz = cra5_api.get_mean_std run by the reference's own code):
+    encode_era5_as_bin(data=) -> decode_from_bin('de_normalized'), cra5_api.py:81-125,153-192."""
+    from cra5_amd.api import cra5_api
+    g = np.load(f"{golden_dir}/era5_stats_ref.npz")
+    api = cra5_api(local_root=str(tmp_path), device="cuda", weights=big)
+    assert np.array_equal(api.mean.cpu().numpy().reshape(-1), g["mean"])
+    assert np.array_equal(api.std.cpu().numpy().reshape(-1), g["std"])
+    assert [api.channels_to_vname[i] for i in range(268)] == list(g["vnames"])
+    mean, std = torch.from_numpy(g["mean"]).view(268, 1, 1), torch.from_numpy(g["std"]).view(268, 1, 1)
+    xn = synth.synth_frame(268, seed=2)
+    frame = xn * std + mean                    # physical units
+    ts = "2024-06-01T00:00:00"
+    r = api.encode_era5_as_bin(ts, save_root=str(tmp_path / "CRA5"), data=frame)
+    assert r["save_path"].endswith("CRA5/2024/2024-06-01T00:00:00.bin")
+    # fused normalisation == the reference's explicit (x - mean) / std followed by compress()
+    y_api = api.encode_to_latent(ts, data=frame)
+    y_ref = big.encode_latent(((frame.to(dev) - api.mean) / api.std).unsqueeze(0), type='float')[0]
+    assert rmse(y_api, y_ref) <= 1e-5
+    e_gold = rmse(sub(y_api, 499), np.load(f"{golden_dir}/full268.npz")["y_sub"])
+    print(f"268 api: y rmse vs reference golden (through de-normalise -> fused normalise) {e_gold:.3e}")
+    assert e_gold <= 2e-5   # the physical-units round trip itself costs ~1 ulp of x
+    d = api.decode_from_bin(ts, return_format='de_normalized')
+    dn = api.decode_from_bin(ts, return_format='normalized')
+    assert d["x_hat"].shape == (268, 721, 1440) or d["x_hat"].shape == (1, 268, 721, 1440)
+    ref = dn["x_hat"].reshape(268, 721, 1440) * api.std + api.mean
+    rel = ((d["x_hat"].reshape(268, 721, 1440) - ref).abs() / api.std).max()
+    assert float(rel) <= 1e-4, float(rel)
+    # per-variable error table in physical units (Readme.md:304-380 layout): finite, sane
+    err = torch.sqrt(((d["x_hat"].reshape(268, 721, 1440) - frame.to(dev)) ** 2).mean(dim=(1, 2))).cpu()
+    assert torch.isfinite(err).all()
 
 
 def test_full268_reduced_precision_mode(big, dev, golden_dir):

@@ -273,3 +273,48 @@ def test_stateful_classes_match_reference_semantics():
     assert s1 == rans_py.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist())
     assert ans.RansDecoder().decode_with_indexes(s1, idx.tolist(), cdf.tolist(), lens.tolist(), offs.tolist()) == sym.tolist()
     assert ans.pmf_to_quantized_cdf([0.25, 0.5, 0.25], 16) == [0, 16384, 49152, 65536]
+
+
+def _kat_cases():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_rans_kat.py")
+    spec = importlib.util.spec_from_file_location("make_rans_kat", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.cases()
+
+
+def test_known_answer_inputs_roundtrip_and_agree():
+    """The KAT inputs of tools/make_rans_kat.py (escape-heavy rows, both escape signs, 2^30
+    payloads, 1- and 2-symbol streams): product == oracle C == oracle Python, and every decoder
+    reads every stream back.  Runs everywhere; the byte-level pin needs rans_kat.npz (next test)."""
+    for name, sym, idx, cdf, ln, off in _kat_cases():
+        a = ops.rans_encode(sym, idx, cdf, ln, off)
+        b = cbind.rans_encode(sym, idx, cdf, ln, off)
+        assert a == b, name
+        if sym.size <= 5000:
+            c = rans_py.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), ln.tolist(),
+                                                          off.tolist())
+            assert a == c, name
+        assert np.array_equal(ops.rans_decode(a, idx, cdf, ln, off), sym), name
+        assert np.array_equal(cbind.rans_decode(a, idx, cdf, ln, off).numpy(), sym), name
+
+
+def test_known_answer_streams_from_real_compressai(golden_dir):
+    """Byte-level pin against a REAL compressai.ans build (rans_interface.cpp:108-284 + ryg_rans
+    rans64.h).  tests/golden/rans_kat.npz is produced by tools/make_rans_kat.py on a machine where
+    `import compressai` works; the build container has no such wheel and the reference cannot build
+    its extension, so until the file is committed byte parity stays 'unpinned' (DESIGN section 2)."""
+    import os
+    path = os.path.join(golden_dir, "rans_kat.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/rans_kat.npz absent: run tools/make_rans_kat.py where compressai is installed")
+    g = np.load(path)
+    assert "SELFTEST" not in str(g["source"]), "rans_kat.npz was written by --selftest: not a known answer"
+    for name, sym, idx, cdf, ln, off in _kat_cases():
+        want = g[f"stream_{name}"].tobytes()
+        assert ops.rans_encode(sym, idx, cdf, ln, off) == want, f"product encoder differs on {name}"
+        assert cbind.rans_encode(sym, idx, cdf, ln, off) == want, f"oracle encoder differs on {name}"
+        assert np.array_equal(ops.rans_decode(want, idx, cdf, ln, off), sym), f"product decoder differs on {name}"
+        assert np.array_equal(cbind.rans_decode(want, idx, cdf, ln, off).numpy(), sym), name
