@@ -116,6 +116,8 @@ def main():
                     help="at most this many frames inside a GPU phase at a time (0 = unlimited)")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="frames of the un-overlapped kernel-timing pass run after the timed region")
+    ap.add_argument("--frame-pool", type=int, default=8,
+                    help="distinct synthetic frames kept resident per rank (frame f uses slot f %% pool)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "8")),
                     help="frames in flight per GPU (host rANS of one frame overlaps GPU work of the others)")
     args = ap.parse_args()
@@ -136,15 +138,24 @@ def main():
     synth.load_synthetic(net, seed=7)
     net = net.to(dev)
     C = args.quality
-    # two distinct frames per rank, resident in HBM before the timed region
-    frames = [synth.synth_frame(C, seed=1000 + 2 * rank + i).unsqueeze(0).to(dev) for i in range(2)]
+    # BASELINE.json configs[3]: the job's frames f = 0 .. world*K-1 are x_f ~ N(0,1) with seed 1000 + f,
+    # rank r owns the contiguous block dist.shard_frames gives it ([8r, 8r+8) of 64 at K = 8).  They are
+    # generated on the device and resident in HBM before the timed region; at most --frame-pool distinct
+    # frames are kept per rank (1.11 GB each), frame f re-using pool slot (f - first) % pool.
+    my_frames = D.shard_frames(world * args.steps, rank, world)
+    pool = max(1, min(args.frame_pool, len(my_frames)))
+    gdev = torch.Generator(device=dev)
+    frames = []
+    for i in range(pool):
+        gdev.manual_seed(1000 + my_frames[0] + i)
+        frames.append(torch.randn((1, C, 721, 1440), generator=gdev, device=dev, dtype=torch.float32))
 
     from cra5_amd.pipeline import FramePipeline
     pipe = FramePipeline(net, workers=args.inflight, device=dev)
 
     # warm-up: W untimed steps (also builds the per-thread workspaces / derived weights)
     net.compress(frames[0])
-    pipe.roundtrip([frames[i % 2] for i in range(max(args.warmup, args.inflight))])
+    pipe.roundtrip([frames[i % pool] for i in range(max(args.warmup, args.inflight))])
     # A fresh box's first process runs ~20 % slow for its first seconds (power state / clocks, page
     # cache, allocator growth): keep running untimed batches until two consecutive ones agree within
     # 3 % (at most --settle-batches of them); reported as `warmup_settle_frames`.
@@ -152,7 +163,7 @@ def main():
     for _ in range(max(0, args.settle_batches)):
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        pipe.roundtrip([frames[i % 2] for i in range(2 * args.inflight)])
+        pipe.roundtrip([frames[i % pool] for i in range(2 * args.inflight)])
         torch.cuda.synchronize()
         tb = time.perf_counter() - tb
         settle_frames += 2 * args.inflight
@@ -179,15 +190,17 @@ def main():
         out = net.compress(x)
         x_hat = net.decompress(out["strings"], out["z_shape"])["x_hat"]
         return out, torch.isfinite(x_hat[0, 0, ::97, ::97]).all()
-    results = pipe.map(round_trip, [frames[i % 2] for i in range(args.steps)])
+    results = pipe.map(round_trip, [frames[i % pool] for i in range(args.steps)])
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
-    rows = [D.frame_stats(rank * args.steps + i, out["strings"]) for i, (out, _) in enumerate(results)]
+    rows = [D.frame_stats(my_frames[i], out["strings"]) for i, (out, _) in enumerate(results)]
     assert all(bool(ok) for _, ok in results)
     elapsed = D.max_over_ranks(elapsed, dev)
     stats = D.gather_stats(rows, dev)  # RCCL all-gather of per-frame bitstream stats
+    # every frame of the job is accounted for exactly once, on every rank
+    assert stats[:, 0].tolist() == list(range(world * args.steps)), "gathered stats do not cover the frame set"
 
     total_frames = world * args.steps
     fps = total_frames / elapsed
@@ -200,11 +213,15 @@ def main():
             "f16 operands / fp32 accumulate in g_a,g_s (reduced precision, configs[4]); hyper-prior fp32-accurate"),
         "data": "synthetic",
         "config": {"workload": f"quality={C} single-frame full encode->bin->decode round trip per step "
-                               f"(BASELINE.json configs[2]); 1 frame/rank/step, frames sharded over ranks",
+                               f"(BASELINE.json configs[2]); 1 frame/rank/step; frames f = 0..{world * args.steps - 1} "
+                               f"(x_f ~ N(0,1), seed 1000+f, configs[3]'s set) block-sharded over ranks",
                    "frame": [C, 721, 1440], "weights": "deterministic synthetic (cra5_amd/synth.py seed 7)",
                    "parallelism": f"frame-sharded x{world}, weights replicated",
                    "frames_in_flight_per_gpu": args.inflight},
         "warmup_settle_frames": settle_frames,
+        "collectives": {"initialized": bool(torch.distributed.is_available() and torch.distributed.is_initialized()),
+                        "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                        "data_path": "none (frames are independent)", "after_timed_region": "all_gather of int64[K,4] stats"},
         "bytes_per_frame": float(stats[:, 1:3].sum().item()) / max(total_frames, 1),
         "model_tflops": FLOP_PER_FRAME * fps / 1e12,
         # whole-path algorithmic rate against the engine's MFMA ceiling (SURVEY 8d "report both")
@@ -285,7 +302,7 @@ def main():
         result["attention_timed_region"] = timed.get("attention")
         net.gpu_exclusive = True
         ops.TIMER = t2 = ops.KernelTimer()
-        pipe.roundtrip([frames[i % 2] for i in range(max(1, args.roofline_steps))])
+        pipe.roundtrip([frames[i % pool] for i in range(max(1, args.roofline_steps))])
         torch.cuda.synchronize()
         ops.TIMER = None
         result.update(roofline_from(t2.summary(), max(1, args.roofline_steps)))

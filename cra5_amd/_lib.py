@@ -62,6 +62,7 @@ SIGNATURES = {
     "cra5_event_record": (c_int, [c_void_p, c_void_p]),
     "cra5_event_elapsed_ms": (c_int, [c_void_p, c_void_p, P(c_float)]),
     "cra5_event_destroy": (c_int, [c_void_p]),
+    "cra5_debug_range_counts": (c_int, [P(ctypes.c_uint64), c_int]),
 }
 
 _lib = None

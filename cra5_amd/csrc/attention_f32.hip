@@ -37,6 +37,8 @@
 #include "../../include/cra5_amd.h"
 #include "split.h"
 
+CRA5_RANGE_TU(attn_f32)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {

@@ -28,6 +28,8 @@
 #include "../../include/cra5_amd.h"
 #include "split.h"
 
+CRA5_RANGE_TU(attn)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));

@@ -9,6 +9,15 @@
 #include "../../include/cra5_amd.h"
 #include "split.h"
 
+CRA5_RANGE_TU(elementwise)
+#ifdef CRA5_RANGE_CHECK
+extern "C" {
+int cra5_range_counts_gemm(unsigned long long *, int);
+int cra5_range_counts_attn(unsigned long long *, int);
+int cra5_range_counts_attn_f32(unsigned long long *, int);
+}
+#endif
+
 namespace {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -665,5 +674,25 @@ int cra5_event_elapsed_ms(void *start, void *stop, float *ms) {
   return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
 }
 int cra5_event_destroy(void *ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+
+int cra5_debug_range_counts(uint64_t *out2, int reset) {
+#ifdef CRA5_RANGE_CHECK
+  if (!out2) return CRA5_ERR_ARG;
+  int rc = (int)hipDeviceSynchronize();
+  if (rc) return rc;
+  unsigned long long h[2] = {0, 0};
+  if ((rc = cra5_range_counts_elementwise(h, reset))) return rc;
+  if ((rc = cra5_range_counts_gemm(h, reset))) return rc;
+  if ((rc = cra5_range_counts_attn(h, reset))) return rc;
+  if ((rc = cra5_range_counts_attn_f32(h, reset))) return rc;
+  out2[0] = h[0];
+  out2[1] = h[1];
+  return rc;
+#else
+  (void)out2;
+  (void)reset;
+  return CRA5_ERR_UNAVAILABLE;
+#endif
+}
 
 }  // extern "C"

@@ -37,6 +37,8 @@
 #include "../../include/cra5_amd.h"
 #include "split.h"
 
+CRA5_RANGE_TU(gemm)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -353,8 +355,8 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
         unsigned short hi[4], lo[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const _Float16 hh = (_Float16)o[c];
-          const _Float16 ll = (_Float16)(o[c] - (float)hh);
+          _Float16 hh, ll;
+          cra5_split(o[c], hh, ll);
           hi[c] = __builtin_bit_cast(unsigned short, hh);
           lo[c] = __builtin_bit_cast(unsigned short, ll);
         }

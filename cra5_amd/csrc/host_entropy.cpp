@@ -132,6 +132,10 @@ int encode_impl(const int32_t *symbols, const int32_t *indexes, size_t n, const 
       return CRA5_ERR_INDEX;
     }
     const Resolved r = resolve(t, symbols[i], ci);
+    if (r.range == 0) {   // malformed table (zero-width bin): would divide by zero in put()
+      std::free(buf);
+      return CRA5_ERR_INDEX;
+    }
     if (r.escape) {
       for (int j = r.n_nibbles - 1; j >= 0; --j) e.put_bits((r.raw >> (j * kBypassBits)) & kBypassMax);
       const uint32_t full = static_cast<uint32_t>(r.n_nibbles) / kBypassMax;
@@ -427,6 +431,7 @@ int cra5_rans_encoder_push(void *enc, const int32_t *symbols, const int32_t *ind
   for (size_t i = 0; i < n; ++i) {
     const int32_t ci = indexes[i];
     if (ci < 0 || ci >= n_cdfs || cdf_sizes[ci] < 2 || cdf_sizes[ci] > cdf_stride) return CRA5_ERR_INDEX;
+    if (resolve(t, symbols[i], ci).range == 0) return CRA5_ERR_INDEX;   // zero-width bin: nothing is buffered
   }
   for (size_t i = 0; i < n; ++i) {
     const Resolved r = resolve(t, symbols[i], indexes[i]);

@@ -29,9 +29,11 @@ def init_from_env(device_type="cuda"):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "nccl" if device_type == "cuda" else "gloo"
+        kw = {}
         if device_type == "cuda":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)   # binds the RCCL communicator to this rank's GPU
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

@@ -61,20 +61,19 @@ class EntropyModel(nn.Module):
         self._host_tables = None
 
     # -- table access ----------------------------------------------------------------
+    # (buffer, name in the "Uninitialized ..." message, name in the "Invalid ... size" message, rank);
+    # the messages are the reference's (entropy_models.py:218-237), incl. its "offsets" for the lengths
+    _TABLES = (("_quantized_cdf", "CDFs", "CDF", 2), ("_offset", "offsets", "offsets", 1),
+               ("_cdf_length", "CDF lengths", "offsets", 1))
+
     def _check(self):
-        """entropy_models.py:218-237."""
-        if self._quantized_cdf.numel() == 0:
-            raise ValueError("Uninitialized CDFs. Run update() first")
-        if len(self._quantized_cdf.size()) != 2:
-            raise ValueError(f"Invalid CDF size {self._quantized_cdf.size()}")
-        if self._offset.numel() == 0:
-            raise ValueError("Uninitialized offsets. Run update() first")
-        if len(self._offset.size()) != 1:
-            raise ValueError(f"Invalid offsets size {self._offset.size()}")
-        if self._cdf_length.numel() == 0:
-            raise ValueError("Uninitialized CDF lengths. Run update() first")
-        if len(self._cdf_length.size()) != 1:
-            raise ValueError(f"Invalid offsets size {self._cdf_length.size()}")
+        """Raise the reference's ValueErrors when update() has not run / a table is mis-shaped."""
+        for attr, what, what_size, rank in self._TABLES:
+            t = getattr(self, attr)
+            if t.numel() == 0:
+                raise ValueError(f"Uninitialized {what}. Run update() first")
+            if t.dim() != rank:
+                raise ValueError(f"Invalid {what_size} size {t.size()}")
 
     def host_tables(self):
         """(cdf, cdf_length, offset) as contiguous int32 numpy arrays, cached: the
@@ -131,31 +130,27 @@ class EntropyBottleneck(EntropyModel):
     """entropy_models.py:333-542."""
 
     def __init__(self, channels, *args, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3), **kwargs):
+        """Parameters of the factorised density (names / shapes / initial values / registration order
+        of entropy_models.py:346-388, so a reference checkpoint loads unchanged): a chain of
+        len(filters)+1 per-channel affine maps 1 -> f0 -> ... -> 1 with gated tanh between them."""
         super().__init__(*args, **kwargs)
-        self.channels = int(channels)
+        C = self.channels = int(channels)
         self.filters = tuple(int(f) for f in filters)
-        self.init_scale = float(init_scale)
-        self.tail_mass = float(tail_mass)
-        filters = (1,) + self.filters + (1,)
-        scale = self.init_scale ** (1 / (len(self.filters) + 1))
-        channels = self.channels
-        for i in range(len(self.filters) + 1):
-            init = np.log(np.expm1(1 / scale / filters[i + 1]))
-            matrix = torch.Tensor(channels, filters[i + 1], filters[i])
-            matrix.data.fill_(init)
-            self.register_parameter(f"_matrix{i:d}", nn.Parameter(matrix))
-            bias = torch.Tensor(channels, filters[i + 1], 1)
-            nn.init.uniform_(bias, -0.5, 0.5)
-            self.register_parameter(f"_bias{i:d}", nn.Parameter(bias))
-            if i < len(self.filters):
-                factor = torch.Tensor(channels, filters[i + 1], 1)
-                nn.init.zeros_(factor)
-                self.register_parameter(f"_factor{i:d}", nn.Parameter(factor))
-        self.quantiles = nn.Parameter(torch.Tensor(channels, 1, 3))
-        init = torch.Tensor([-self.init_scale, 0, self.init_scale])
-        self.quantiles.data = init.repeat(self.quantiles.size(0), 1, 1)
-        target = np.log(2 / self.tail_mass - 1)
-        self.register_buffer("target", torch.Tensor([-target, 0, target]))
+        self.init_scale, self.tail_mass = float(init_scale), float(tail_mass)
+        widths = (1,) + self.filters + (1,)
+        n_maps = len(widths) - 1
+        per_map_scale = self.init_scale ** (1.0 / n_maps)
+        for i, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            # softplus^-1 of the per-map gain, so that the composed maps start at `init_scale`
+            m0 = float(np.log(np.expm1(1.0 / per_map_scale / fan_out)))
+            self.register_parameter(f"_matrix{i}", nn.Parameter(torch.full((C, fan_out, fan_in), m0)))
+            self.register_parameter(f"_bias{i}", nn.Parameter(torch.empty(C, fan_out, 1).uniform_(-0.5, 0.5)))
+            if i + 1 < n_maps:
+                self.register_parameter(f"_factor{i}", nn.Parameter(torch.zeros(C, fan_out, 1)))
+        q0 = torch.tensor([-self.init_scale, 0.0, self.init_scale])
+        self.quantiles = nn.Parameter(q0.repeat(C, 1, 1))
+        logit_tail = float(np.log(2.0 / self.tail_mass - 1.0))
+        self.register_buffer("target", torch.tensor([-logit_tail, 0.0, logit_tail]))
         self._packed = None
 
     def _get_medians(self):
@@ -220,22 +215,32 @@ class EntropyBottleneck(EntropyModel):
 class GaussianConditional(EntropyModel):
     """entropy_models.py:545-685."""
 
+    @staticmethod
+    def _validate_scale_table(scale_table):
+        """None, or a non-empty ascending list / tuple of positive scales (errors of
+        entropy_models.py:556-569)."""
+        if scale_table is None:
+            return
+        if not isinstance(scale_table, (list, tuple)):
+            raise ValueError(f'Invalid type for scale_table "{type(scale_table)}"')
+        if len(scale_table) < 1:
+            raise ValueError(f'Invalid scale_table length "{len(scale_table)}"')
+        ascending = all(a <= b for a, b in zip(scale_table, scale_table[1:]))
+        if not ascending or min(scale_table) <= 0:
+            raise ValueError(f'Invalid scale_table "({scale_table})"')
+
     def __init__(self, scale_table, *args, scale_bound=0.11, tail_mass=1e-9, **kwargs):
         super().__init__(*args, **kwargs)
-        if not isinstance(scale_table, (type(None), list, tuple)):
-            raise ValueError(f'Invalid type for scale_table "{type(scale_table)}"')
-        if isinstance(scale_table, (list, tuple)) and len(scale_table) < 1:
-            raise ValueError(f'Invalid scale_table length "{len(scale_table)}"')
-        if scale_table and (scale_table != sorted(scale_table) or any(s <= 0 for s in scale_table)):
-            raise ValueError(f'Invalid scale_table "({scale_table})"')
+        self._validate_scale_table(scale_table)
         self.tail_mass = float(tail_mass)
         if scale_bound is None and scale_table:
-            scale_bound = scale_table[0]
-        if scale_bound <= 0:
+            scale_bound = scale_table[0]     # entropy_models.py:573-574
+        if scale_bound is None or scale_bound <= 0:
             raise ValueError("Invalid parameters")
         self.lower_bound_scale = _LowerBound(scale_bound)
-        self.register_buffer("scale_table", self._prepare_scale_table(scale_table) if scale_table else torch.Tensor())
-        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]) if scale_bound is not None else None)
+        table = self._prepare_scale_table(scale_table) if scale_table else torch.Tensor()
+        self.register_buffer("scale_table", table)
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
 
     @staticmethod
     def _prepare_scale_table(scale_table):

@@ -23,17 +23,20 @@ class KernelTimer:
     achieved rate over the timed region."""
 
     def __init__(self, sample_every=1):
-        """sample_every = n: bracket every n-th launch only (per calling thread).  Event records
+        """(thread-safe: frame threads record concurrently)
+        sample_every = n: bracket every n-th launch only (per calling thread).  Event records
         are queue packets between the kernels; at ~400 timed launches per frame they cost ~5 %
         of the frame rate, sampling keeps the timed region honest."""
         self.records = {}   # kind -> list of (start_ev, stop_ev, work)
         self._free = []
+        self._lock = threading.Lock()
         self.sample_every = max(1, int(sample_every))
         self._tls = threading.local()
 
     def _ev(self):
-        if self._free:
-            return self._free.pop()
+        with self._lock:
+            if self._free:
+                return self._free.pop()
         e = ctypes.c_void_p()
         check(lib().cra5_event_create(ctypes.byref(e)), "cra5_event_create")
         return e
@@ -53,12 +56,15 @@ class KernelTimer:
             return
         e = self._ev()
         check(lib().cra5_event_record(e, _stream()), "cra5_event_record")
-        self.records.setdefault(kind, []).append((start_ev, e, work))
+        with self._lock:
+            self.records.setdefault(kind, []).append((start_ev, e, work))
 
     def summary(self):
         """kind -> dict(launches, work, ms). Synchronises on the recorded events."""
         out = {}
-        for kind, recs in self.records.items():
+        with self._lock:
+            records, self.records = self.records, {}
+        for kind, recs in records.items():
             ms_tot, work = 0.0, 0.0
             for s, e, w in recs:
                 ms = ctypes.c_float()
@@ -67,7 +73,6 @@ class KernelTimer:
                 work += w
                 self._free += [s, e]
             out[kind] = dict(launches=len(recs), work=work, ms=ms_tot)
-        self.records = {}
         return out
 
 
@@ -342,8 +347,11 @@ def gaussian_conditional(scales, means, scale_table, y=None, sym_in=None, want=(
         assert y.is_contiguous() and y.numel() == n
     if sym_in is not None:
         assert sym_in.is_contiguous() and sym_in.numel() == n and sym_in.dtype == torch.int32
+    n_table = 0 if scale_table is None else scale_table.numel()   # no table: no indexes (forward() before update())
+    if n_table == 0 and "idx" in want:
+        raise ValueError("gaussian_conditional: indexes requested without a scale table (run update())")
     check(lib().cra5_gaussian_conditional_f32(_p(y), _p(sym_in), _p(scales), _p(means), _p(scale_table),
-                                              scale_table.numel(), float(scale_bound), float(lik_bound), _p(o["idx"]),
+                                              n_table, float(scale_bound), float(lik_bound), _p(o["idx"]),
                                               _p(o["sym"]), _p(o["y_hat"]), _p(o["lik"]), n, _stream()),
           "cra5_gaussian_conditional_f32")
     return {k: v for k, v in o.items() if v is not None}

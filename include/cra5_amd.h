@@ -33,6 +33,7 @@ extern "C" {
 #define CRA5_ERR_PMF_STEAL (-5) /* no bin can donate frequency                     */
 #define CRA5_ERR_STREAM (-6)    /* truncated / corrupt rANS stream                 */
 #define CRA5_ERR_ARG (-7)
+#define CRA5_ERR_UNAVAILABLE (-8) /* entry point not compiled into this build flavour */
 
 int cra5_abi_version(void);
 
@@ -244,6 +245,13 @@ int cra5_event_create(void **ev);
 int cra5_event_record(void *ev, void *stream);
 int cra5_event_elapsed_ms(void *start, void *stop, float *ms);
 int cra5_event_destroy(void *ev);
+
+/* Range audit of the split-f16 producers (csrc/split.h): out[0] = elements with |x| >= 65504 (clipped
+ * by the saturating split), out[1] = non-finite elements, counted since the last reset by every
+ * LayerNorm / GEMM-epilogue / attention / patch-gather store.  Only in the `rangecheck` build flavour
+ * (python -m cra5_amd.build --flavour rangecheck, -DCRA5_RANGE_CHECK); CRA5_ERR_UNAVAILABLE otherwise.
+ * Synchronises the device. */
+int cra5_debug_range_counts(uint64_t *out2, int reset);
 
 #ifdef __cplusplus
 }

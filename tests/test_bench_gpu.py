@@ -30,3 +30,21 @@ def test_bench_json_contract():
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.05 < r["frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_rccl_single_rank():
+    """The N > 1 launch path with the hardware at hand: bench.py under torch.distributed.run with ONE
+    rank and CRA5_FORCE_DIST=1, so RCCL initialisation (device-bound communicator), the barrier, the
+    max-over-ranks all-reduce and the all-gather of the per-frame stats all execute on the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+           "--steps", "3", "--warmup", "1", "--settle-batches", "0", "--roofline-steps", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, CRA5_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert d["collectives"]["backend"] == "nccl" and d["collectives"]["initialized"] is True

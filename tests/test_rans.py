@@ -121,6 +121,18 @@ def test_errors_are_codes_not_ub():
         ops.rans_decode(s[:4], good_idx, cdf, lens, offs)  # truncated
     with pytest.raises(ValueError):
         ops.rans_encode(sym, good_idx[:3], cdf, lens, offs)
+    # a malformed table with a zero-width bin (cdf[v+1] == cdf[v]) is an error code, not a SIGFPE,
+    # in the one-shot and in the buffered encoder (the reference divides by zero here)
+    bad = cdf.copy()
+    v = int(-offs[0])          # the bin symbol 0 of row 0 lands in
+    bad[0, v + 1] = bad[0, v]
+    with pytest.raises(Cra5Error):
+        ops.rans_encode(sym, good_idx, bad, lens, offs)
+    from cra5_amd import ans
+    e = ans.BufferedRansEncoder()
+    with pytest.raises(Cra5Error):
+        e.encode_with_indexes(sym.tolist(), good_idx.tolist(), bad.tolist(), lens.tolist(), offs.tolist())
+    assert len(e.flush()) == 8   # nothing was buffered by the failed push
 
 
 def test_decoder_bucket_tables_wide_and_narrow_rows():
@@ -318,3 +330,27 @@ def test_known_answer_streams_from_real_compressai(golden_dir):
         assert cbind.rans_encode(sym, idx, cdf, ln, off) == want, f"oracle encoder differs on {name}"
         assert np.array_equal(ops.rans_decode(want, idx, cdf, ln, off), sym), f"product decoder differs on {name}"
         assert np.array_equal(cbind.rans_decode(want, idx, cdf, ln, off).numpy(), sym), name
+
+
+def test_host_coder_under_address_and_ub_sanitizers():
+    """The `asan` build flavour (cra5_amd/build.py; the reference's setup.py:72-75 has only a -O0 -g
+    -UNDEBUG switch): the whole rANS suite above re-run in a subprocess against a host coder compiled
+    with -fsanitize=address,undefined.  Any out-of-bounds read of a stream / table or signed overflow
+    in the escape arithmetic aborts the subprocess."""
+    import os
+    import subprocess
+    import sys
+    from cra5_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = B.build(flavour="asan")
+    rt = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"],
+                                 text=True).strip()
+    if not os.path.exists(rt):
+        pytest.skip("clang asan runtime not present")
+    env = dict(os.environ, CRA5_LIB=lib, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_rans.py"), "-q", "-x",
+                        "-k", "not sanitizers", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "passed" in r.stdout

@@ -1,0 +1,94 @@
+"""Range audit of the split-f16 engine (needs the `rangecheck` build flavour):
+
+    CRA5_LIB=cra5_amd/_flavours/libcra5_rangecheck.so python tools/range_audit.py [--model thin|268]
+
+Runs (1) GEMM + LayerNorm + attention on activations scaled by 1e-6, 1, 1e4 and 1e5 and (2) a full
+encode -> decode of the model on a synthetic frame, and prints ONE JSON line with, per case, the
+number of split-f16 stores that saw |x| >= 65 504 (clipped by the saturating split, csrc/split.h)
+or a non-finite value, and the accuracy against float64.  With a real checkpoint loaded through
+cra5_api the same counters answer "do this model's activations stay in range" (VERDICT r1).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from cra5_amd import ops, synth  # noqa: E402
+from cra5_amd._lib import lib  # noqa: E402
+
+
+def counts(reset=True):
+    out = (ctypes.c_uint64 * 2)()
+    rc = lib().cra5_debug_range_counts(out, int(reset))
+    if rc:
+        raise SystemExit(f"cra5_debug_range_counts rc={rc}: run with CRA5_LIB=<rangecheck flavour>")
+    return int(out[0]), int(out[1])
+
+
+def rel(a, b):
+    b = b.double().cpu()
+    return float(torch.sqrt(torch.mean((a.double().cpu() - b) ** 2)) / torch.sqrt(torch.mean(b ** 2)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="thin")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    res = {}
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 2048, 1024, 1024
+    a0 = torch.randn(M, K, generator=g)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(dev)
+    sw = ops.split_f16(w, "auto")
+    counts()
+    for name, scale in (("1e-6", 1e-6), ("1", 1.0), ("1e4", 1e4), ("1e5", 1e5)):
+        x = (a0 * scale).to(dev)
+        sa = ops.split_f16(x)
+        c_in = counts()
+        out_s = ops.SplitMat.empty(M, N, dev, zero=True)
+        out = ops.gemm_nt_split(sa, sw, out_split=out_s)
+        c_out = counts()
+        ref = (a0.double() * scale).clamp(-131008, 131008) @ w.double().cpu().t()
+        # LayerNorm is scale-invariant: its split output must not depend on the input scale
+        ga, be = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+        sm = ops.SplitMat.empty(M, K, dev)
+        ops.layernorm(x, ga, be, 1e-6, out_split=sm, want_f32=False)
+        ln = sm.to_float()
+        c_ln = counts()
+        res[name] = dict(split_in=c_in, gemm_out=c_out, layernorm=c_ln, gemm_rel_rmse=rel(out, ref),
+                         gemm_finite=bool(torch.isfinite(out).all()), ln_finite=bool(torch.isfinite(ln).all()),
+                         ln_rms=float(ln.pow(2).mean().sqrt()))
+    # attention on large-magnitude q/k/v (head dim 64): softmax must stay finite, outputs bounded by max|v|
+    qkv = torch.randn(576, 3 * 128, generator=g) * 200.0
+    qs = ops.split_f16(qkv.to(dev))
+    pad = ops.split_f16(torch.zeros(1, 3 * 128, device=dev))
+    att = ops.SplitMat.empty(576, 128, dev, zero=True)
+    o = ops.window_attention_split(qs, pad, 2, 24, 24, 24, 24, out=torch.empty(576, 128, device=dev), out_split=att)
+    q, k, v = qkv.double().view(576, 3, 2, 64).permute(1, 2, 0, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 64 ** -0.5, -1) @ v).permute(1, 0, 2).reshape(576, 128)
+    res["attention_x200"] = dict(counts=counts(), finite=bool(torch.isfinite(o).all()), rel_rmse=rel(o, ref))
+    # the model end to end
+    if a.model == "268":
+        from cra5_amd.zoo import vaeformer_pretrained
+        net, C = vaeformer_pretrained(quality=268, pretrained=False), 268
+    else:
+        from cra5_amd.vaeformer import VAEformer
+        net, C = VAEformer(0, **synth.thin_model_kwargs()), 8
+    synth.load_synthetic(net, seed=7)
+    net = net.to(dev)
+    x = synth.synth_frame(C, seed=2).unsqueeze(0).to(dev)
+    counts()
+    out = net.compress(x)
+    xh = net.decompress(out["strings"], out["z_shape"])["x_hat"]
+    res["model_" + a.model] = dict(counts=counts(), finite=bool(torch.isfinite(xh).all()))
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
