@@ -58,6 +58,10 @@ SIGNATURES = {
     "cra5_rans_resolve_symbols_i32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "cra5_gdn_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "cra5_small_gemm_nt_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                         c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int,
+                                         c_int, c_void_p]),
+    "cra5_hyper_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "cra5_event_create": (c_int, [P(c_void_p)]),
     "cra5_event_record": (c_int, [c_void_p, c_void_p]),
     "cra5_event_elapsed_ms": (c_int, [c_void_p, c_void_p, P(c_float)]),

@@ -15,6 +15,7 @@ extern "C" {
 int cra5_range_counts_gemm(unsigned long long *, int);
 int cra5_range_counts_attn(unsigned long long *, int);
 int cra5_range_counts_attn_f32(unsigned long long *, int);
+int cra5_range_counts_hyper(unsigned long long *, int);
 }
 #endif
 
@@ -685,6 +686,7 @@ int cra5_debug_range_counts(uint64_t *out2, int reset) {
   if ((rc = cra5_range_counts_gemm(h, reset))) return rc;
   if ((rc = cra5_range_counts_attn(h, reset))) return rc;
   if ((rc = cra5_range_counts_attn_f32(h, reset))) return rc;
+  if ((rc = cra5_range_counts_hyper(h, reset))) return rc;
   out2[0] = h[0];
   out2[1] = h[1];
   return rc;

@@ -197,6 +197,56 @@ def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=Non
     return out
 
 
+def small_gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True,
+                        unembed=None):
+    """gemm_nt_split for the hyper-prior sizes (csrc/hyper.hip).  unembed = (Hz, Wz, p1, p2): `out` is the
+    image [N / (p1*p2), Hz*p1, Wz*p2] and w's rows are in (c, p1, p2) order (HyperpriorDecoder un-embed)."""
+    _devs(a.data, w.data)
+    _dev(bias, res, out)
+    M, N = a.rows, w.rows
+    assert a.Kp == w.Kp and a.K == w.K, (a.K, w.K)
+    assert a.scale_inv == 1.0, "activations are split unscaled"
+    if unembed is not None:
+        Hz, Wz, p1, p2 = unembed
+        assert out is not None and out.is_contiguous() and out.numel() == M * N
+    else:
+        Hz = Wz = p1 = p2 = 0
+        if out is None and want_f32:
+            out = torch.empty((M, N), device=a.data.device, dtype=torch.float32)
+    if out_split is not None:
+        assert out_split.rows == M and out_split.K == N
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
+    ev = TIMER.start() if TIMER is not None else None
+    check(lib().cra5_small_gemm_nt_split(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
+                                         _row_stride(out) if (out is not None and unembed is None) else 0,
+                                         _p(out_split.data) if out_split is not None else None,
+                                         out_split.Kp if out_split is not None else 0, _p(bias), _p(res),
+                                         _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv),
+                                         flags, Hz, Wz, p1, p2, _stream()), "cra5_small_gemm_nt_split")
+    if ev is not None:
+        TIMER.stop("gemm_nt_split_small", ev, 2.0 * M * N * a.K)
+    return out
+
+
+def hyper_attention(qkv, heads, out=None, out_split=None, want_f32=True):
+    """Global attention of the hyper-prior blocks: qkv fp32 [n, 3C] -> [n, C] (exact fp32 MFMA)."""
+    _dev(qkv, out)
+    n, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.is_contiguous()
+    if out is None and want_f32:
+        out = torch.empty((n, C), device=qkv.device, dtype=torch.float32)
+    if out_split is not None:
+        assert out_split.rows == n and out_split.K == C
+    ev = TIMER.start() if TIMER is not None else None
+    check(lib().cra5_hyper_attention_f32(_p(qkv), _p(out), _p(out_split.data) if out_split is not None else None,
+                                         out_split.Kp if out_split is not None else 0, n, C, heads,
+                                         float((C // heads) ** -0.5), _stream()), "cra5_hyper_attention_f32")
+    if ev is not None:
+        TIMER.stop("hyper_attention_f32", ev, 4.0 * n * n * C)
+    return out if out is not None else out_split
+
+
 def layernorm(x, gamma, beta, eps=1e-6, out=None, out_split=None, want_f32=True):
     _dev(x, gamma, beta, out)
     rows, D = x.shape

@@ -508,6 +508,41 @@ class VAEformer(nn.Module):
         return y
 
     # ---- hyper-prior ----------------------------------------------------------------------
+    # h_a / h_s always run on ONE fixed engine - the small-M split-f16 GEMM and the exact-fp32 attention
+    # of csrc/hyper.hip - whatever CRA5_GEMM / CRA5_ATTN / CRA5_GEMM_TILE / the precision mode say: the
+    # decoder re-derives the CDF indexes from h_s and a single flipped index desynchronises the rANS
+    # stream, so the encode and the decode side must not be able to pick different kernels.
+    def _hy_mm(self, a, key, w, bias=None, res=None, gelu=False, out=None, out_name=None, unembed=None):
+        W = self._wsplit(key, w)
+        if out_name is not None:
+            sm = self._sbuf(out_name, a.rows, W.rows)
+            ops.small_gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False)
+            return sm
+        return ops.small_gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out=out, unembed=unembed)
+
+    def _hy_ln(self, x, norm, name):
+        sm = self._sbuf(name, x.shape[0], x.shape[1])
+        ops.layernorm(x, norm.weight, norm.bias, 1e-6, out_split=sm, want_f32=False)
+        return sm
+
+    def _hy_block(self, blk, pre, t):
+        """vit_nlc.py:282-287 with global attention (vit_nlc.py:94-112) on the [n, d] fp32 stream t, in place."""
+        n, d = t.shape
+        h = self._hy_ln(t, blk.norm1, f"hy_h{d}")
+        qkv = self._hy_mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias,
+                          out=self._buf(f"hy_qkv{d}", (n, 3 * d)))
+        att = self._sbuf(f"hy_att{d}", n, d, zero=True)   # pad columns stay zero
+        if (d // blk.heads) in (64, 72):
+            ops.hyper_attention(qkv, blk.heads, out_split=att, want_f32=False)
+        else:   # other head dims: the generic exact-fp32 kernel (same on both sides)
+            ops.window_attention(qkv, blk.attn.qkv.bias, blk.heads, self.Hz, self.Wz, self.Hz, self.Wz, out_split=att,
+                                 want_f32=False)
+        self._hy_mm(att, pre + ".attn.proj", blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t, out=t)
+        h = self._hy_ln(t, blk.norm2, f"hy_h{d}")
+        hid = self._hy_mm(h, pre + ".mlp.fc1", blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias, gelu=True,
+                          out_name=f"hy_hid{d}")
+        self._hy_mm(hid, pre + ".mlp.fc2", blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias, res=t, out=t)
+
     def _h_a_frame(self, y):
         """y [L, Hp, Wp] -> z [Cz, Hz*Wz] (vit_nlc.py:488-551)."""
         cfg = self.cfg
@@ -515,19 +550,16 @@ class VAEformer(nn.Module):
         zh, zw = cfg['h_patch']
         n = self.Hz * self.Wz
         K = y.shape[0] * zh * zw
-        if self.gemm_mode == "split":
-            cols = ops.im2col(y, zh, zw, zh, zw, out_split=self._sbuf("hcols", n, K, zero=True))
-        else:
-            cols = ops.im2col(y, zh, zw, zh, zw, out=self._buf("hcols", (n, K)))
-        t = self._buf(f"t{d}", (n, d))
-        self._mm(cols, "h_a.patch_embed.proj", self.h_a.patch_embed.proj.weight, bias=self.h_a.patch_embed.proj.bias,
-                 res=self.h_a.pos_embed[0], out=t)
+        cols = ops.im2col(y, zh, zw, zh, zw, out_split=self._sbuf("hcols", n, K, zero=True))
+        t = self._buf(f"hy_t{d}", (n, d))
+        self._hy_mm(cols, "h_a.patch_embed.proj", self.h_a.patch_embed.proj.weight,
+                    bias=self.h_a.patch_embed.proj.bias, res=self.h_a.pos_embed[0], out=t)
         for i, blk in enumerate(self.h_a.blocks):
-            self._block(blk, f"h_a.blocks.{i}", t, t, (self.Hz, self.Wz))
+            self._hy_block(blk, f"h_a.blocks.{i}", t)
         m = self.h_a.quan_mlp
-        u = self._mm(self._act(t, "ha_t_s"), "h_a.quan_mlp.fc1", m.fc1.weight, bias=m.fc1.bias, gelu=True,
-                     out_name="ha_u")
-        ztok = self._mm(u, "h_a.quan_mlp.fc2", m.fc2.weight, bias=m.fc2.bias)
+        u = self._hy_mm(ops.split_f16(t, out=self._sbuf("ha_t_s", n, d)), "h_a.quan_mlp.fc1", m.fc1.weight,
+                        bias=m.fc1.bias, gelu=True, out_name="ha_u")
+        ztok = self._hy_mm(u, "h_a.quan_mlp.fc2", m.fc2.weight, bias=m.fc2.bias)
         return ops.transpose(ztok)  # [Cz, n]
 
     def _h_s_frame(self, z_hat):
@@ -540,15 +572,25 @@ class VAEformer(nn.Module):
         n = self.Hz * self.Wz
         ztok = ops.transpose(z_hat)  # [n, Cz]
         m = self.h_s.post_quan_mlp
-        u = self._mm(self._act(ztok, "hs_z_s"), "h_s.post_quan_mlp.fc1", m.fc1.weight, bias=m.fc1.bias, gelu=True,
-                     out_name="hs_u")
-        t = self._buf(f"t{d}", (n, d))
-        self._mm(u, "h_s.post_quan_mlp.fc2", m.fc2.weight, bias=m.fc2.bias, out=t)
+        u = self._hy_mm(ops.split_f16(ztok, out=self._sbuf("hs_z_s", n, ztok.shape[1])), "h_s.post_quan_mlp.fc1",
+                        m.fc1.weight, bias=m.fc1.bias, gelu=True, out_name="hs_u")
+        t = self._buf(f"hy_t{d}", (n, d))
+        self._hy_mm(u, "h_s.post_quan_mlp.fc2", m.fc2.weight, bias=m.fc2.bias, out=t)
         for i, blk in enumerate(self.h_s.blocks):
-            self._block(blk, f"h_s.blocks.{i}", t, t, (self.Hz, self.Wz))
-        h = self._ln(t, self.h_s.norm, f"h{d}")
-        lin = self._mm(h, "h_s.final", self.h_s.final.weight)
-        params = ops.pixel_shuffle(lin, self.Hz, self.Wz, zh, zw)  # [2L, Hp, Wp]
+            self._hy_block(blk, f"h_s.blocks.{i}", t)
+        h = self._hy_ln(t, self.h_s.norm, f"hy_h{d}")
+        F = self.h_s.final.weight.shape[0]
+        cout = F // (zh * zw)
+        if zw == 4:
+            # un-embed `b h w (p1 p2 c) -> b c (h p1) (w p2)` fused into the GEMM store: weight rows
+            # re-ordered to (c, p1, p2) once, a lane writes 4 horizontal pixels of the image
+            wps = self._derive("ws.h_s.final.ps", self.h_s.final.weight, lambda w: ops.split_f16(
+                w.view(zh, zw, cout, -1).permute(2, 0, 1, 3).reshape(F, -1).contiguous(), "auto"))
+            params = torch.empty((cout, self.Hz * zh, self.Wz * zw), device=self.device, dtype=torch.float32)
+            ops.small_gemm_nt_split(h, wps, out=params, unembed=(self.Hz, self.Wz, zh, zw))
+        else:
+            lin = self._hy_mm(h, "h_s.final", self.h_s.final.weight)
+            params = ops.pixel_shuffle(lin, self.Hz, self.Wz, zh, zw)  # [2L, Hp, Wp]
         L = params.shape[0] // 2
         return params[:L], params[L:]
 

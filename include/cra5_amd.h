@@ -240,6 +240,25 @@ int cra5_rans_resolve_symbols_i32(const int32_t *symbols, const int32_t *indexes
 int cra5_gdn_f32(const float *x, const float *beta, const float *gamma, float *y, int B, int C,
                  int HW, int inverse, void *stream);
 
+/* ---- hyper-prior path (HyperpriorEncoder / HyperpriorDecoder, vit_nlc.py:488-551, 696-748) --------
+ * Latency-bound sizes (648 tokens x 360 channels): csrc/hyper.hip.  Both are deterministic (fixed
+ * reduction order) - h_s runs on the encode and on the decode side and must agree bit for bit. */
+
+/* cra5_gemm_nt_split for small M: one wave per 32 x 32..128 tile, operands straight from L2, optional
+ * in-block split-K.  Same arguments; C_split pad columns (N .. ldc_split_kp) are written as zeros.
+ * ps_Hz > 0 selects the fused un-embed store of HyperpriorDecoder (vit_nlc.py:672-679,
+ * `b h w (p1 p2 c) -> b c (h p1) (w p2)`): M = ps_Hz * ps_Wz tokens, the N = Cout * ps_p1 * ps_p2 weight
+ * rows must be in (c, p1, p2) order (ps_p2 must be 4), and C is the image [Cout][ps_Hz*ps_p1][ps_Wz*4]. */
+int cra5_small_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw_kp, float *C, int ldc,
+                             uint16_t *C_split, int ldc_split_kp, const float *bias, const float *res, int ldr,
+                             int M, int N, int Kp, float wscale_inv, int flags, int ps_Hz, int ps_Wz, int ps_p1,
+                             int ps_p2, void *stream);
+
+/* Attention.forward (vit_nlc.py:94-112) over all n_tok tokens, exact fp32 MFMA, head dim 72 | 64:
+ * qkv fp32 [n_tok][3C] -> out fp32 [n_tok][C] and / or out_split (pad columns must already be zero). */
+int cra5_hyper_attention_f32(const float *qkv, float *out, uint16_t *out_split, int split_kp, int n_tok, int C,
+                             int heads, float scale, void *stream);
+
 /* Device-side timing helpers for bench.py (HIP events on the launch stream). */
 int cra5_event_create(void **ev);
 int cra5_event_record(void *ev, void *stream);

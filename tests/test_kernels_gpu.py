@@ -431,3 +431,80 @@ def test_split_f16_range_guard(dev):
     # logits of +-3e5: the softmax is one-hot and an ulp of a logit moves whole rows -> 1e-4-class, finite
     assert res["attention_x200"]["rel_rmse"] < 1e-3
     assert res["model_thin"]["counts"] == [0, 0] and res["model_thin"]["finite"]
+
+
+@pytest.mark.parametrize("M,N,K", [(648, 1080, 360), (648, 360, 360), (648, 1440, 360), (648, 360, 1440),
+                                   (648, 360, 4096), (648, 256, 360), (648, 256, 256), (162, 432, 144),
+                                   (648, 8192, 360), (100, 77, 52), (2000, 3000, 96)])
+def test_small_gemm_split_matches_fp64_and_big_engine(dev, M, N, K):
+    """csrc/hyper.hip small-M GEMM (all dispatch branches: 1 / 4 / 8-way in-block split-K, 32 / 64 / 128-column
+    wave tiles) against float64 and against the big-tile engine, with every epilogue flag and the
+    split-f16 output incl. its zero pad columns."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    a = torch.randn(M, K, generator=g) * 1.3
+    w = torch.randn(N, K, generator=g) * (1.0 / np.sqrt(K))
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double()) + r.double()
+    sa, sw = ops.split_f16(a.to(dev)), ops.split_f16(w.to(dev), "auto")
+    out_s = ops.SplitMat.empty(M, N, dev)          # NOT zero-initialised: the kernel must write the pad
+    out_s.data.fill_(0x7e00)                        # f16 NaN pattern everywhere
+    out = ops.small_gemm_nt_split(sa, sw, bias=b.to(dev), res=r.to(dev), gelu=True, out_split=out_s)
+    big = ops.gemm_nt_split(sa, sw, bias=b.to(dev), res=r.to(dev), gelu=True)
+    e, e_big = relerr(out, ref), relerr(big, ref)
+    print(f"small gemm {M}x{N}x{K}: rel {e:.2e} (big engine {e_big:.2e})")
+    assert e < 2e-6 and e <= 1.5 * e_big + 1e-8
+    assert float((out_s.to_float() - out).abs().max()) <= 2 ** -21 * float(out.abs().max()) + 2 ** -24
+    raw = out_s.data.view(torch.float16).view(M, out_s.Kp // 32, 2, 32)
+    if out_s.Kp > N:
+        pad = raw.permute(0, 1, 3, 2).reshape(M, out_s.Kp, 2)[:, N:, :]
+        assert float(pad.float().abs().max()) == 0.0      # pad columns: zeros, not NaN
+    # plain (no epilogue) + determinism: two launches are bit-identical
+    p1 = ops.small_gemm_nt_split(sa, sw)
+    p2 = ops.small_gemm_nt_split(sa, sw)
+    assert torch.equal(p1, p2)
+    assert relerr(p1, a.double() @ w.double().t()) < 2e-6
+
+
+def test_small_gemm_unembed_store(dev):
+    """HyperpriorDecoder un-embed fused into the GEMM store (vit_nlc.py:672-679): rearrange
+    'b h w (p1 p2 c) -> b c (h p1) (w p2)' of Linear(360 -> 16*512) == the kernel's image output when the
+    weight rows are pre-permuted to (c, p1, p2) order."""
+    g = torch.Generator().manual_seed(9)
+    Hz, Wz, p, cout, d = 18, 36, 4, 512, 360
+    a = torch.randn(Hz * Wz, d, generator=g)
+    w = torch.randn(p * p * cout, d, generator=g) * 0.05
+    lin = (a.double() @ w.double().t()).view(Hz, Wz, p, p, cout)          # (h, w, p1, p2, c)
+    ref = lin.permute(4, 0, 2, 1, 3).reshape(cout, Hz * p, Wz * p)
+    wps = w.view(p, p, cout, d).permute(2, 0, 1, 3).reshape(p * p * cout, d).contiguous()
+    img = torch.empty(cout, Hz * p, Wz * p, device=dev)
+    ops.small_gemm_nt_split(ops.split_f16(a.to(dev)), ops.split_f16(wps.to(dev), "auto"), out=img,
+                            unembed=(Hz, Wz, p, p))
+    assert relerr(img, ref) < 2e-6
+    # and it equals the un-fused route (row-major GEMM + pixel_shuffle kernel) to fp32 rounding
+    lin32 = ops.small_gemm_nt_split(ops.split_f16(a.to(dev)), ops.split_f16(w.to(dev), "auto"))
+    img2 = ops.pixel_shuffle(lin32, Hz, Wz, p, p)
+    assert relerr(img, img2.double()) < 1e-6
+
+
+@pytest.mark.parametrize("n,heads,hd", [(648, 5, 72), (648, 2, 72), (100, 3, 72), (41, 2, 64), (17, 1, 72)])
+def test_hyper_attention_matches_fp64(dev, n, heads, hd):
+    """Key-split exact-fp32 attention (csrc/hyper.hip) vs float64 softmax attention and vs the round-1
+    window_attention_f32 kernel; ragged last query / key tiles; softmax spike rows."""
+    g = torch.Generator().manual_seed(n + heads)
+    C = heads * hd
+    qkv = torch.randn(n, 3 * C, generator=g)
+    qkv[3, :C] *= 6.0                       # a peaked row
+    q, k, v = qkv.double().view(n, 3, heads, hd).permute(1, 2, 0, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).permute(1, 0, 2).reshape(n, C)
+    dq = qkv.to(dev)
+    so = ops.SplitMat.empty(n, C, dev, zero=True)
+    out = ops.hyper_attention(dq, heads, out=torch.empty(n, C, device=dev), out_split=so)
+    e = relerr(out, ref)
+    print(f"hyper attention n={n} heads={heads} hd={hd}: rel {e:.2e}")
+    assert e < 2e-6
+    assert float((so.to_float() - out).abs().max()) <= 2 ** -21 * float(out.abs().max()) + 2 ** -24
+    assert torch.equal(out, ops.hyper_attention(dq, heads))          # deterministic
+    if hd == 72 and n == 648:
+        old = ops.window_attention(dq, torch.zeros(3 * C, device=dev), heads, 18, 36, 18, 36)
+        assert relerr(out, old.double()) < 1e-6
