@@ -38,6 +38,64 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (
 FLOP_PER_FRAME = 11.57e12      # encode 6.132 + decode 5.415 + hyper-prior
 
 
+def host_cpu_info():
+    """(model string, physical cores, hardware threads) of the box."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    threads = os.cpu_count() or 1
+    return model, (len(phys) or threads), threads
+
+
+def cpu_baseline_full(quality, n_threads):
+    """BASELINE.json configs[0] for real: ONE full compress -> decompress of the oracle
+    (oracle/torch_ref.py: the reference's math path, materialised attention scores; oracle C rANS on one
+    thread) on x = torch.rand(1, C, 721, 1440) seed 0 (Readme.md:139), same synthetic weights as the GPU
+    run.  Minutes of CPU and ~20 GB of RAM: not part of the default run (`--cpu-baseline full`)."""
+    from cra5_amd import synth
+    from cra5_amd.zoo import vaeformer_pretrained
+    from oracle import cbind
+    from oracle import torch_ref as R
+    torch.set_num_threads(n_threads)
+    net = vaeformer_pretrained(quality=quality, pretrained=False)   # parameter container only (CPU tensors)
+    synth.load_synthetic(net, seed=7)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    del net
+    cfg = R.cfg_268(quality)
+    tb = R.tables(sd, cbind.pmf_to_cdf)
+    x = synth.synth_frame(quality, seed=0, kind="uniform").unsqueeze(0)
+    spans = {}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        out, _ = R.compress(x, sd, cfg, tb, cbind.rans_encode)
+        t1 = time.perf_counter()
+        rec = R.decompress(out["strings"], out["z_shape"], sd, cfg, tb, cbind.rans_decode)["x_hat"]
+        t2 = time.perf_counter()
+    assert rec.shape == x.shape and bool(torch.isfinite(rec).all())
+    spans = {"compress_s": t1 - t0, "decompress_s": t2 - t1,
+             "y_bytes": len(out["strings"][0][0]), "z_bytes": len(out["strings"][1][0])}
+    model, phys, threads = host_cpu_info()
+    return {"value": 1.0 / (t2 - t0), "unit": "frames/s", "cores": n_threads, "physical_cores": phys,
+            "hardware_threads": threads, "cpu": model, "kind": "port",
+            "sample": (f"ONE full frame, BASELINE configs[0]: oracle/torch_ref.py compress {t1 - t0:.1f}s + decompress "
+                       f"{t2 - t1:.1f}s on {n_threads} torch threads (rANS on 1), x = rand seed 0, quality={quality}"),
+            "spans": spans}
+
+
 def cpu_baseline(quality, n_threads):
     """Bounded CPU sample of the same workload with the oracle (kind = "port")."""
     from cra5_amd import synth
@@ -83,11 +141,14 @@ def cpu_baseline(quality, n_threads):
     t_pe, t_win, t_glob = t1 - t0, t2 - t1, t3 - t2
     # 13 encoder + 12 decoder blocks = 18 windowed + 7 global; un-embed costs about one patch-embed
     est = 2 * t_pe + 18 * t_win + 7 * t_glob + (t5 - t4) + (t6 - t5)
-    return {"value": 1.0 / est, "unit": "frames/s", "cores": n_threads, "kind": "port",
+    model, phys, threads = host_cpu_info()
+    return {"value": 1.0 / est, "unit": "frames/s", "cores": n_threads, "physical_cores": phys,
+            "hardware_threads": threads, "cpu": model, "kind": "port", "extrapolated": True,
             "sample": (f"oracle/torch_ref.py on {n_threads} host threads, quality={quality}, full 721x1440 frame: "
                        f"patch-embed {t_pe:.2f}s + 1 windowed block {t_win:.2f}s + 1 global block (materialised "
                        f"scores) {t_glob:.2f}s, + oracle C rANS encode {t5 - t4:.2f}s / decode {t6 - t5:.2f}s of "
-                       f"2.65M symbols; frame time extrapolated as 2*pe + 18*win + 7*glob + rANS = {est:.1f}s")}
+                       f"2.65M symbols; frame time extrapolated as 2*pe + 18*win + 7*glob + rANS = {est:.1f}s; the "
+                       f"un-extrapolated figure (`--cpu-baseline full`, one whole frame) is committed under profiles/")}
 
 
 def main():
@@ -102,6 +163,10 @@ def main():
     ap.add_argument("--settle-batches", type=int, default=8,
                     help="extra untimed warm-up batches (2 x inflight frames each) until the batch time settles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("sample", "full", "only-full"), default="sample",
+                    help="sample (default): bounded ~20 s sample, extrapolated; full: one whole frame through the "
+                         "oracle (BASELINE configs[0], minutes); only-full: just that, no GPU run (prints its JSON)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0 = physical cores)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-sample", type=int, default=7,
                     help="inside the timed region bracket every n-th GEMM / attention launch with HIP events "
@@ -124,6 +189,10 @@ def main():
     from cra5_amd import ops, synth
     from cra5_amd.zoo import vaeformer_pretrained
 
+    cpu_threads = args.cpu_threads or host_cpu_info()[1]
+    if args.cpu_baseline == "only-full":
+        print(json.dumps({"cpu_baseline": cpu_baseline_full(args.quality, cpu_threads)}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only product path")
     rank, world, local = D.init_from_env("cuda")
@@ -312,7 +381,8 @@ def main():
                 "launches of concurrent frames overlap and per-launch durations are inflated")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(args.quality, os.cpu_count() or 1)
+            result["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(
+                args.quality, cpu_threads)
         except Exception as e:  # noqa: BLE001
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

@@ -33,6 +33,7 @@
 // output in chunks of <= 8192 (two-level sum).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/cra5_amd.h"
 #include "split.h"
@@ -83,11 +84,19 @@ __device__ unsigned long long g_gemm_trace[5 * 8192];
 #define CRA5_TRACE(slot)
 #endif
 
-template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3>
+// Stream-K work split of the persistent variant (SK = true): `dp_rounds` full rounds of one tile per
+// work-group, then the remaining `sk_tiles` tiles cut along K into P equal iteration ranges.
+struct SkArgs {
+  float *ws;            // [2 P] partial accumulator tiles of BM x BN floats (MFMA register layout)
+  unsigned *counters;   // [sk_tiles] arrivals per split tile, zero between launches (the last arriver resets)
+  int dp_rounds, sk_tiles;
+};
+
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3, bool SK = false>
 __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_split_kernel(
     const unsigned short *__restrict__ A, long lda, const unsigned short *__restrict__ W, long ldw, float *C,
     int ldc, unsigned short *Cs, long ldcs, const float *__restrict__ bias, const float *res, int ldr, int M,
-    int N, int Kp, float wscale_inv, int flags, int tiles_n) {
+    int N, int Kp, float wscale_inv, int flags, int tiles_n, SkArgs sk) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int NT = WM * WN * 64;
@@ -106,13 +115,52 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 5 + 4] = clock64();
 #endif
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = pid / tiles_n, tn = pid % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
+  const int nk_all = Kp / BK;
+
+  // ---- persistent stream-K schedule (SK): this work-group's items ---------------------------------
+  // Iterations of the sk tiles are numbered tile-major (tile t: [t nk, (t+1) nk)); work-group v owns
+  // [v I / P, (v+1) I / P), at most two tile segments because I / P < nk: `hi` (the beginning of the
+  // later tile) runs FIRST, then the data-parallel tiles, `lo` (the end of the earlier tile) LAST.
+  // A segment that is not a whole tile parks its accumulators in the workspace; the last of a tile's
+  // contributors to arrive (atomic counter) adds them up in k order - a fixed order - and runs the
+  // epilogue.  Nobody ever waits for another work-group: concurrent kernels cannot deadlock.
+  __shared__ int sk_last;
+  const int P = gridDim.x;
+  long sk_s = 0, sk_e = 0, sk_total = 0;
+  int n_items = 1, n_hi = 0;
+  if (SK) {
+    sk_total = (long)sk.sk_tiles * nk_all;
+    sk_s = (long)pid * sk_total / P;
+    sk_e = (long)(pid + 1) * sk_total / P;
+    const bool two = sk_e > sk_s && (sk_s / nk_all) != ((sk_e - 1) / nk_all);
+    n_hi = two ? 1 : 0;
+    n_items = n_hi + sk.dp_rounds + ((sk_e > sk_s) ? 1 : 0);
+  }
+  for (int item = 0; item < n_items; ++item) {
+  int tile = pid, ka = 0, kb = nk_all, my_slot = 0;
+  if (SK) {
+    if (item < n_hi) {                                   // hi segment: [tile_hi * nk, sk_e)
+      const int t = (int)((sk_e - 1) / nk_all);
+      tile = sk.dp_rounds * P + t;
+      ka = 0;
+      kb = (int)(sk_e - (long)t * nk_all);
+      my_slot = 2 * pid + 1;
+    } else if (item < n_hi + sk.dp_rounds) {
+      tile = (item - n_hi) * P + pid;
+    } else {                                             // lo segment: [sk_s, min(sk_e, end of its tile))
+      const int t = (int)(sk_s / nk_all);
+      tile = sk.dp_rounds * P + t;
+      ka = (int)(sk_s - (long)t * nk_all);
+      kb = (int)(((sk_e < (long)(t + 1) * nk_all) ? sk_e : (long)(t + 1) * nk_all) - (long)t * nk_all);
+      my_slot = 2 * pid;
+    }
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
 
   // Staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 1 KB straight into LDS -
   // no staging VGPRs, no ds_write pass.  The destination is wave-uniform base + lane*16, i.e. LINEAR
@@ -144,9 +192,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
       const int row_ = (isA ? grow : grow - BM) + lrow;
       const int lpiece = (NPROD == 3) ? ((lane & 7) ^ ((row_ >> 1) & 7)) : ((lane & 3) ^ ((row_ >> 2) & 3));
       if (isA)
-        src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + lpiece * 8;
+        src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + lpiece * 8 + (size_t)ka * 64;
       else
-        src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + lpiece * 8;
+        src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + lpiece * 8 + (size_t)ka * 64;
     }
   }
   // (the builtin only exists in the device pass; the host pass just needs the launch stub)
@@ -226,7 +274,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   //     stage tile kt just vacated | MFMA(F1)
   // Measured (tools/gemm_trace.py variants): with the barrier at the end of the step the matrix
   // pipe idled through barrier skew + the first ds_reads of the new stage, 20 of 78 us per tile.
-  const int nk = Kp / BK;
+  const int nk = kb - ka;
   half8 f0ah[TM], f0al[TM], f0bh[TN], f0bl[TN], f1ah[TM], f1al[TM], f1bh[TN], f1bl[TN];
   CRA5_STAGE_LOAD(0);
   __syncthreads();   // (hipcc drains vmcnt before the barrier: tile 0 has landed for everyone)
@@ -289,83 +337,158 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
     for (int c = 0; c < 4; ++c)
       if (nw + c < N) bv[c] = bias[nw + c];
   }
+  // stream-K bookkeeping of a split tile (see the schedule comment above)
+  constexpr int TILE_F = BM * BN;
+  int p_first = 0, p_last = -1;
+  long sk_t0 = 0;
+  // MODE 0: accumulators -> outputs.  MODE 1 (split tile): accumulators -> this segment's partial tile in the
+  // workspace, raw fp32 [BM][BN] (published by the agent-scope release of the arrival counter).  MODE 2 (last
+  // arriver of a split tile): sum of ALL its partial tiles in k order (our own re-read, so the association
+  // does not depend on who arrived last) -> outputs.  Two instantiations touch `acc`, MODE 2 does not:
+  // the 128 accumulator registers are dead while partial tiles stream through.
+  auto epilogue = [&](auto mode_tag) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int mrow0 = m0 + (wm * TM + i) * 32;
-    if (mrow0 >= M) break;               // wave-uniform
+    for (int i = 0; i < TM; ++i) {
+      const int mrow0 = m0 + (wm * TM + i) * 32;
+      if (mrow0 >= M) break;               // wave-uniform
+      float4 v4[32 / RPI];
+      if (MODE != 2) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r];
-        if (LONGK) v += master[i][j][r];
-        stg[(4 * h + (r & 3) + 8 * (r >> 2)) * LDW + j * 32 + l31] = v;
-      }
-    __builtin_amdgcn_wave_barrier();
-    float4 v4[32 / RPI];
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r];
+            if (LONGK) v += master[i][j][r];
+            stg[(4 * h + (r & 3) + 8 * (r >> 2)) * LDW + j * 32 + l31] = v;
+          }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int p = 0; p < 32 / RPI; ++p) v4[p] = *reinterpret_cast<const float4 *>(stg + (p * RPI + er) * LDW + ec);
-    __builtin_amdgcn_wave_barrier();
-    float4 r4[32 / RPI];
-    if (has_res) {
+        for (int p = 0; p < 32 / RPI; ++p) v4[p] = *reinterpret_cast<const float4 *>(stg + (p * RPI + er) * LDW + ec);
+        __builtin_amdgcn_wave_barrier();
+      } else {
 #pragma unroll
-      for (int p = 0; p < 32 / RPI; ++p) {
-        const int m = mrow0 + p * RPI + er;
-        r4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && nw < N) {
-          const float *rp = res + (size_t)m * ldr + nw;
-          if (vecR && nw + 3 < N) {
-            r4[p] = *reinterpret_cast<const float4 *>(rp);
-          } else {
-            r4[p].x = rp[0];
-            if (nw + 1 < N) r4[p].y = rp[1];
-            if (nw + 2 < N) r4[p].z = rp[2];
-            if (nw + 3 < N) r4[p].w = rp[3];
+        for (int p = 0; p < 32 / RPI; ++p) v4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int pp = p_first; pp <= p_last; ++pp) {
+          const long ps = (long)pp * sk_total / P;
+          const int slot = 2 * pp + ((ps < sk_t0) ? 1 : 0);   // range began in an earlier tile: its hi segment
+          const float *wsp = sk.ws + (size_t)slot * TILE_F + (size_t)((wm * TM + i) * 32 + er) * BN + wn * COLS + ec;
+#pragma unroll
+          for (int p = 0; p < 32 / RPI; ++p) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(wsp + (size_t)p * RPI * BN);
+            v4[p].x += t4.x;
+            v4[p].y += t4.y;
+            v4[p].z += t4.z;
+            v4[p].w += t4.w;
           }
         }
       }
-    }
+      if (MODE == 1) {
+        float *wsp = sk.ws + (size_t)my_slot * TILE_F + (size_t)((wm * TM + i) * 32 + er) * BN + wn * COLS + ec;
 #pragma unroll
-    for (int p = 0; p < 32 / RPI; ++p) {
-      const int m = mrow0 + p * RPI + er;
-      if (m >= M || nw >= N) continue;
-      float o[4] = {v4[p].x, v4[p].y, v4[p].z, v4[p].w};
-      const float rr[4] = {r4[p].x, r4[p].y, r4[p].z, r4[p].w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v = o[c] * wscale_inv + bv[c];
-        if (do_gelu) v = gelu_erf(v);
-        if (has_res) v += rr[c];
-        o[c] = (nw + c < N) ? v : 0.f;
+        for (int p = 0; p < 32 / RPI; ++p) *reinterpret_cast<float4 *>(wsp + (size_t)p * RPI * BN) = v4[p];
+        continue;
       }
-      if (C) {
-        float *cp = C + (size_t)m * ldc + nw;
-        if (vecC && nw + 3 < N) {
-          *reinterpret_cast<float4 *>(cp) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
-          cp[0] = o[0];
-          if (nw + 1 < N) cp[1] = o[1];
-          if (nw + 2 < N) cp[2] = o[2];
-          if (nw + 3 < N) cp[3] = o[3];
+      float4 r4[32 / RPI];
+      if (has_res) {
+#pragma unroll
+        for (int p = 0; p < 32 / RPI; ++p) {
+          const int m = mrow0 + p * RPI + er;
+          r4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < M && nw < N) {
+            const float *rp = res + (size_t)m * ldr + nw;
+            if (vecR && nw + 3 < N) {
+              r4[p] = *reinterpret_cast<const float4 *>(rp);
+            } else {
+              r4[p].x = rp[0];
+              if (nw + 1 < N) r4[p].y = rp[1];
+              if (nw + 2 < N) r4[p].z = rp[2];
+              if (nw + 3 < N) r4[p].w = rp[3];
+            }
+          }
         }
       }
-      if (Cs) {
-        // split layout: 128-byte chunk per 32 columns = [32 hi | 32 lo]; 4 columns -> 8 B + 8 B.
-        // Columns >= N inside the group are written as zero (they are K padding of the consumer).
-        unsigned short hi[4], lo[4];
+#pragma unroll
+      for (int p = 0; p < 32 / RPI; ++p) {
+        const int m = mrow0 + p * RPI + er;
+        if (m >= M) continue;
+        if (nw >= N) {
+          // pad columns N .. ldcs/2 of the split output are the zero K padding of the consumer
+          if (Cs && nw < (int)(ldcs >> 1)) {
+            unsigned short *sp = Cs + (size_t)m * ldcs + (nw >> 5) * 64 + (nw & 31);
+            *reinterpret_cast<uint2 *>(sp) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(sp + 32) = make_uint2(0u, 0u);
+          }
+          continue;
+        }
+        float o[4] = {v4[p].x, v4[p].y, v4[p].z, v4[p].w};
+        const float rr[4] = {r4[p].x, r4[p].y, r4[p].z, r4[p].w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          _Float16 hh, ll;
-          cra5_split(o[c], hh, ll);
-          hi[c] = __builtin_bit_cast(unsigned short, hh);
-          lo[c] = __builtin_bit_cast(unsigned short, ll);
+          float v = o[c] * wscale_inv + bv[c];
+          if (do_gelu) v = gelu_erf(v);
+          if (has_res) v += rr[c];
+          o[c] = (nw + c < N) ? v : 0.f;
         }
-        unsigned short *sp = Cs + (size_t)m * ldcs + (nw >> 5) * 64 + (nw & 31);
-        *reinterpret_cast<uint2 *>(sp) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
-        *reinterpret_cast<uint2 *>(sp + 32) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+        if (C) {
+          float *cp = C + (size_t)m * ldc + nw;
+          if (vecC && nw + 3 < N) {
+            *reinterpret_cast<float4 *>(cp) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            cp[0] = o[0];
+            if (nw + 1 < N) cp[1] = o[1];
+            if (nw + 2 < N) cp[2] = o[2];
+            if (nw + 3 < N) cp[3] = o[3];
+          }
+        }
+        if (Cs) {
+          // split layout: 128-byte chunk per 32 columns = [32 hi | 32 lo]; 4 columns -> 8 B + 8 B.
+          // Columns >= N inside the group are written as zero (they are K padding of the consumer).
+          unsigned short hi[4], lo[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            _Float16 hh, ll;
+            cra5_split(o[c], hh, ll);
+            hi[c] = __builtin_bit_cast(unsigned short, hh);
+            lo[c] = __builtin_bit_cast(unsigned short, ll);
+          }
+          unsigned short *sp = Cs + (size_t)m * ldcs + (nw >> 5) * 64 + (nw & 31);
+          *reinterpret_cast<uint2 *>(sp) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
+          *reinterpret_cast<uint2 *>(sp + 32) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
+        }
       }
     }
+  };
+  if (SK && (ka != 0 || kb != nk_all)) {
+    epilogue(std::integral_constant<int, 1>{});
+    // contributors of this tile: work-groups whose ranges meet [t nk, (t+1) nk)
+    const int t_sk = tile - sk.dp_rounds * P;
+    sk_t0 = (long)t_sk * nk_all;
+    const long t1 = sk_t0 + nk_all;
+    p_first = (int)(sk_t0 * P / sk_total);
+    p_last = (int)((t1 - 1) * P / sk_total);
+    while ((long)(p_first + 1) * sk_total / P <= sk_t0) ++p_first;
+    while ((long)p_first * sk_total / P > sk_t0) --p_first;
+    while ((long)(p_last + 1) * sk_total / P <= t1 - 1) ++p_last;
+    while ((long)p_last * sk_total / P > t1 - 1) --p_last;
+    // every wave's partial stores have reached this XCD's L2 (s_waitcnt vmcnt(0) precedes the barrier); ONE
+    // thread then releases at agent scope (L2 write-back: the other XCDs read the workspace through memory),
+    // counts the arrival, and - if it was the last - acquires before anybody reads the other partial tiles.
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned n_contrib = (unsigned)(p_last - p_first + 1);
+      const unsigned prev = __hip_atomic_fetch_add(sk.counters + t_sk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (prev + 1 == n_contrib);
+      if (last) __hip_atomic_store(sk.counters + t_sk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sk_last = last;
+    }
+    __syncthreads();
+    if (sk_last) epilogue(std::integral_constant<int, 2>{});
+  } else {
+    epilogue(std::integral_constant<int, 0>{});
   }
+  if (SK) __syncthreads();   // the next item's LDS-DMA overwrites the epilogue scratch
+  }  // item loop
   CRA5_TRACE(3);
 #ifdef CRA5_GEMM_TRACE
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 5 + 4] = clock64() - g_gemm_trace[blockIdx.x * 5 + 4];
@@ -391,7 +514,37 @@ int launch(const unsigned short *A, long lda, const unsigned short *W, long ldw,
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK, STAGES, NPROD>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
-                     st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n);
+                     st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n,
+                     SkArgs{nullptr, nullptr, 0, 0});
+  return (int)hipGetLastError();
+}
+
+constexpr int SK_BM = 256, SK_BN = 256;
+constexpr size_t SK_COUNTER_BYTES = 4096;   // >= 4 * P
+
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
+// persistent hybrid stream-K launch of the 256 x 256 tile kernel: one resident work-group per CU
+int launch_sk(const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C, int ldc,
+              unsigned short *Cs, long ldcs, const float *bias, const float *res, int ldr, int M, int N, int Kp,
+              float wscale_inv, int flags, void *workspace, hipStream_t st) {
+  const int tiles_m = (M + SK_BM - 1) / SK_BM, tiles_n = (N + SK_BN - 1) / SK_BN;
+  const int T = tiles_m * tiles_n, P = cu_count();
+  SkArgs sk;
+  sk.counters = reinterpret_cast<unsigned *>(workspace);
+  sk.ws = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + SK_COUNTER_BYTES);
+  sk.dp_rounds = T / P;
+  sk.sk_tiles = T - sk.dp_rounds * P;
+  hipLaunchKernelGGL((gemm_nt_split_kernel<2, 4, 4, 2, false, 2, 3, true>), dim3(P), dim3(512), 0, st, A, lda, W, ldw,
+                     C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n, sk);
   return (int)hipGetLastError();
 }
 
@@ -461,6 +614,50 @@ extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t 
     return 0;
   }
   return gemm_dispatch(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+}
+
+extern "C" size_t cra5_gemm_sk_workspace_bytes(void) {
+  return SK_COUNTER_BYTES + (size_t)2 * cu_count() * SK_BM * SK_BN * sizeof(float);
+}
+
+extern "C" int cra5_gemm_nt_split_sk(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw_kp, float *C, int ldc,
+                                     uint16_t *C_split, int ldc_split_kp, const float *bias, const float *res, int ldr,
+                                     int M, int N, int Kp, float wscale_inv, int flags, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+  // mode: 0 = never (plain launch; DEFAULT - measured on MI355X the schedule loses),
+  // 1 = where the round-count model predicts a gain, 2 = whenever legal
+  static const int mode = [] {
+    const char *e = getenv("CRA5_GEMM_SK");
+    return e ? atoi(e) : 0;
+  }();
+  const int P = cu_count();
+  const long T = (long)((M + SK_BM - 1) / SK_BM) * ((N + SK_BN - 1) / SK_BN);
+  const int nk = Kp / BK;
+  bool legal = workspace && workspace_bytes >= cra5_gemm_sk_workspace_bytes() && ((uintptr_t)workspace & 15) == 0 &&
+               Kp > 0 && (Kp % BK) == 0 && Kp <= 8192 && !(flags & CRA5_GEMM_HI_ONLY) && M >= 1024 && N >= 1024 &&
+               (size_t)4 * P <= SK_COUNTER_BYTES;
+  const long R = T % P;
+  legal = legal && R != 0 && R * nk >= P && T >= P / 2;   // something to split, every work-group gets iterations
+  const bool forced = flags & CRA5_GEMM_SK_FORCE;
+  bool use = legal && mode != 0 && !(flags & CRA5_GEMM_SK_OFF);
+  if (forced) use = legal;
+  flags &= ~(CRA5_GEMM_SK_FORCE | CRA5_GEMM_SK_OFF);
+  if (use && mode == 1 && !forced) {
+    // plain launch: ceil(T / P) rounds (N = 1024: 192-row tiles, one round of 0.75-size tiles); stream-K:
+    // T / P rounds + ~0.12 round of fix-up traffic
+    const double plain = (N >= 2048) ? (double)((T + P - 1) / P) : 0.75 * (double)((((M + 191) / 192) * ((N + 255) / 256) + P - 1) / P);
+    use = (double)T / P + 0.12 < plain;
+  }
+  if (!use)
+    return cra5_gemm_nt_split(A, lda_kp, W, ldw_kp, C, ldc, C_split, ldc_split_kp, bias, res, ldr, M, N, Kp, wscale_inv,
+                              flags, stream);
+  if (!A || !W || (!C && !C_split) || lda_kp < Kp || ldw_kp < Kp || (lda_kp % 32) || (ldw_kp % 32)) return CRA5_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return CRA5_ERR_ARG;
+  if ((flags & CRA5_EPI_BIAS) && !bias) return CRA5_ERR_ARG;
+  if ((flags & CRA5_EPI_RES) && !res) return CRA5_ERR_ARG;
+  if (C_split && (ldc_split_kp % 32 || ldc_split_kp < N)) return CRA5_ERR_ARG;
+  return launch_sk(A, 2L * lda_kp, W, 2L * ldw_kp, C, ldc, C_split, 2L * ldc_split_kp, bias, res, ldr, M, N, Kp,
+                   wscale_inv, flags, workspace, (hipStream_t)stream);
 }
 
 extern "C" int cra5_split_f16(const float *x, int ldx, uint16_t *out, int rows, int K, int Kp, float scale,

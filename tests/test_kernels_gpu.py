@@ -506,3 +506,35 @@ def test_hyper_attention_matches_fp64(dev, n, heads, hd):
     if hd == 72 and n == 648:
         old = ops.window_attention(dq, torch.zeros(3 * C, device=dev), heads, 18, 36, 18, 36)
         assert relerr(out, old.double()) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(10368, 4096, 1024), (10368, 1024, 4096), (10368, 1024, 1024), (10368, 3072, 1024),
+                                   (10368, 2048, 512), (4000, 1280, 2048), (10368, 1024, 7392)])
+def test_gemm_stream_k_schedule(dev, M, N, K):
+    """Persistent hybrid stream-K schedule of the big split-f16 GEMM: same numbers as the plain launch up to the
+    association of the K split (fp32: <= a few ulp), fp32-accurate against float64, bit-reproducible from run to
+    run (split tiles are summed in k order by whoever arrives last), counters left at zero, all epilogues."""
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double()) + r.double()
+    sa, sw = ops.split_f16(a.to(dev)), ops.split_f16(w.to(dev), "auto")
+    bd, rd = b.to(dev), r.to(dev)
+    ws = ops.gemm_sk_workspace(dev)
+    os_ = ops.SplitMat.empty(M, N, dev, zero=True)
+    plain = ops.gemm_nt_split(sa, sw, bias=bd, res=rd, gelu=True, sk_ws=ws, sk=False)
+    sk1 = ops.gemm_nt_split(sa, sw, bias=bd, res=rd, gelu=True, sk_ws=ws, sk=True, out_split=os_)
+    sk2 = ops.gemm_nt_split(sa, sw, bias=bd, res=rd, gelu=True, sk_ws=ws, sk=True)
+    torch.cuda.synchronize()
+    e_p, e_s = relerr(plain, ref), relerr(sk1, ref)
+    print(f"stream-K {M}x{N}x{K}: rel err plain {e_p:.2e}, stream-K {e_s:.2e}, max |diff| {float((sk1 - plain).abs().max()):.2e}")
+    assert torch.equal(sk1, sk2)                       # deterministic
+    assert e_s < 2e-6 and e_s <= 1.2 * e_p + 1e-8
+    assert float((sk1 - plain).abs().max()) <= 1e-5 * float(plain.abs().max())
+    assert float((os_.to_float() - sk1).abs().max()) <= 2 ** -21 * float(sk1.abs().max()) + 2 ** -24
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0      # arrival counters back to zero
+    # no-epilogue + fp32-only output, auto schedule
+    p2 = ops.gemm_nt_split(sa, sw, sk_ws=ws)
+    assert relerr(p2, a.double() @ w.double().t()) < 2e-6
