@@ -284,7 +284,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
 
   // Waves past the end of the window (q_tok < 0 for all lanes) run the same instruction stream
   // on the pad row and store nothing: one code path, no divergent barriers.
+#ifdef ATT_NOLOOP   /* timing experiment: prologue + epilogue only */
+  for (int j = 0; j < 0; ++j) {
+#else
   for (int j = 0; j < n_tiles; ++j) {
+#endif
     const int kb = (j + 1) & 1, vb = j & 1;
     // tile j's running max is known before its softmax starts (mloc was reduced in the shadow of
     // the previous tile's PV MFMAs), so the rare O rescale sits at the top and everything below

@@ -386,7 +386,10 @@ class VAEformer(nn.Module):
         return b[1]
 
     def _sk_workspace(self):
-        """Per-thread (= per stream) stream-K workspace of the big GEMM (csrc/gemm_split_f16.hip)."""
+        """Per-thread (= per stream) stream-K workspace of the big GEMM (csrc/gemm_split_f16.hip); only
+        when the experimental schedule is switched on (CRA5_GEMM_SK=1|2): it is off by default."""
+        if os.environ.get("CRA5_GEMM_SK", "0") in ("", "0"):
+            return None
         ws = getattr(self._tls, "sk_ws", None)
         if ws is None or ws.device != self.device:
             ws = self._tls.sk_ws = ops.gemm_sk_workspace(self.device)
