@@ -501,3 +501,27 @@ def test_rate_estimate_predicts_stream_size(thin, dev):
     print(f"thin: estimated {bits / 8:.0f} bytes, coded {real / 8:.0f} bytes ({100 * (real / bits - 1):+.1f} %)")
     assert 0.6 * bits <= real <= 1.25 * bits
     assert metrics.estimated_bpp(out, 721 * 1440) == pytest.approx(bits / (721 * 1440))
+
+
+def test_api_batch_methods_pinned_pipeline(thin, dev, tmp_path):
+    """encode_era5_batch / decode_batch (frames streamed through the frame pipeline with pinned host staging):
+    every frame's .bin and reconstruction equal the single-frame cra5_api methods'."""
+    from cra5_amd.api import cra5_api
+    api = cra5_api(local_root=str(tmp_path), device="cuda", weights=thin)
+    api._mean_flat = torch.linspace(-1, 1, 8, device=dev)
+    api._std_flat = torch.linspace(0.5, 2, 8, device=dev)
+    api.mean, api.std = api._mean_flat.view(8, 1, 1), api._std_flat.view(8, 1, 1)
+    frames = [(synth.synth_frame(8, seed=s) * api.std.cpu() + api.mean.cpu()).numpy() for s in (3, 4, 5, 6, 7)]
+    stamps = [f"2024-06-01T{h:02d}:00:00" for h in range(5)]
+    res = api.encode_era5_batch(stamps, data=frames, save_root=str(tmp_path / "CRA5"), workers=3)
+    assert [r["save_path"].rsplit("/", 1)[1] for r in res] == [s + ".bin" for s in stamps]
+    out = np.empty((5, 8, 721, 1440), dtype=np.float32)
+    rec = api.decode_batch(stamps, out=out, workers=3)
+    rec_n = api.decode_batch(stamps[:2], return_format="normalized", workers=2)
+    for i, ts in enumerate(stamps):
+        one = api.encode_era5_as_bin(ts, save_root=str(tmp_path / "single"), data=frames[i])
+        assert open(one["save_path"], "rb").read() == open(res[i]["save_path"], "rb").read()
+        d = api.decode_from_bin(ts, return_format="de_normalized")["x_hat"]
+        assert np.array_equal(d.cpu().numpy().reshape(8, 721, 1440), out[i]) and rec[i] is not None
+    dn = api.decode_from_bin(stamps[1], return_format="normalized")["x_hat"]
+    assert np.array_equal(dn.cpu().numpy().reshape(8, 721, 1440), rec_n[1])
