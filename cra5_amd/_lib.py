@@ -55,6 +55,9 @@ SIGNATURES = {
     "cra5_col2im_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cra5_transpose_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cra5_pixel_shuffle_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cra5_conv_im2col_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
+    "cra5_deconv_col2im_f32": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),
+    "cra5_unary_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p]),
     "cra5_gaussian_conditional_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                               c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cra5_entropy_bottleneck_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,

@@ -207,6 +207,67 @@ class cra5_api:
         return dict(output=output, reading_time=st2 - st1, encoding_time=st3 - st2, saving_time=st4 - st3,
                     save_path=file_url)
 
+    # ------------------------------------------------------------------ visualisation (cra5_api.py:273-341)
+    @staticmethod
+    def _plt():
+        import matplotlib
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+        return plt
+
+    @staticmethod
+    def _host(a):
+        return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+    def show_image(self, reconstruct_data, time_stamp, show_variables=('z_500', 'q_500', 'u_500', 'v_500', 't_500', 'w_500'),
+                   save_images=True, save_path=None, data=None):
+        """Original / reconstruction / |difference| panels per variable (cra5_api.py:273-315).  `data`: the
+        original frame when the NetCDF files are not on disk.  Returns the figure path."""
+        plt = self._plt()
+        original = self._host(data) if data is not None else self.read_data_from_nc(time_stamp)
+        rec = self._host(reconstruct_data)
+        rec = rec.reshape(rec.shape[-3:])
+        rows = [(original[self.vname_to_channels[v]], rec[self.vname_to_channels[v]]) for v in show_variables]
+        fig, axs = plt.subplots(len(rows), 3, figsize=(20, 3 * len(rows)), squeeze=False)
+        for i, (ori, new) in enumerate(rows):
+            for j, (img, title) in enumerate(((ori, "Original"), (new, "Reconstructed"), (np.abs(ori - new), "Difference"))):
+                im = axs[i, j].imshow(img, cmap='jet')
+                axs[i, j].set_title(f'{show_variables[i]}_{title}')
+                fig.colorbar(im, ax=axs[i, j])
+        plt.tight_layout()
+        fig_path = (f'{save_path}/{time_stamp}_rconstruction.png' if save_path is not None else
+                    f'{self.local_root}/CRA5_vis/{time_stamp[:4]}/{time_stamp}_reconstruction.png')
+        os.makedirs(os.path.dirname(fig_path), exist_ok=True)
+        if save_images:
+            fig.savefig(fig_path)
+        plt.close(fig)
+        return fig_path
+
+    def show_latent(self, latent, time_stamp, show_channels=(0, 10, 20, 30, 40, 50, 60, 70, 80), save_images=True,
+                    save_path=None):
+        """One panel per latent channel (cra5_api.py:317-341; the reference's len//4-row grid drops the 9th
+        default channel and indexes past its axes - the grid here has enough rows).  Returns the figure path."""
+        plt = self._plt()
+        lat = self._host(latent)
+        lat = lat.reshape(lat.shape[-3:])
+        n = len(show_channels)
+        fig, axs = plt.subplots((n + 3) // 4, 4, figsize=(24, 3 * ((n + 3) // 4)), squeeze=False)
+        axs = axs.flatten()
+        for i, ch in enumerate(show_channels):
+            im = axs[i].imshow(lat[ch], cmap='jet')
+            axs[i].set_title(f'Channel_{ch}')
+            fig.colorbar(im, ax=axs[i])
+        for ax in axs[n:]:
+            ax.axis('off')
+        plt.tight_layout()
+        fig_path = (f'{save_path}/{time_stamp}_latent.png' if save_path is not None else
+                    f'{self.local_root}/CRA5_vis/{time_stamp[:4]}/{time_stamp}_latent.png')
+        os.makedirs(os.path.dirname(fig_path), exist_ok=True)
+        if save_images:
+            fig.savefig(fig_path)
+        plt.close(fig)
+        return fig_path
+
     # ------------------------------------------------------------------ many frames at a time
     # The single-frame methods above hand a pageable host array to the device synchronously (one 1.11 GB
     # H2D per frame, 18-80 ms, nothing else running meanwhile) and return x_hat on the device.  A

@@ -375,6 +375,63 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------
+// CNN zoo plumbing (models/utils.py:128-147 conv / deconv: kernel k, stride s, padding k/2,
+// output_padding s-1): Conv2d = zero-padded patch gather + GEMM, ConvTranspose2d = GEMM + the gather
+// form of the overlap-add (every output pixel sums its <= ceil(k/s)^2 contributions in a fixed order:
+// deterministic, no atomics).  Small images, latency-irrelevant: one thread per element.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_im2col_kernel(const float *__restrict__ x, unsigned short *__restrict__ cols_s,
+                                                          int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
+                                                          int pw, int Ho, int Wo, int Kp) {
+  const int K = C * kh * kw;
+  const size_t total = (size_t)Ho * Wo * Kp;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % Kp);
+    const size_t tok = e / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int j = k % kw, i = (k / kw) % kh, c = k / (kw * kh);
+      const int yo = (int)(tok / Wo), xo = (int)(tok % Wo);
+      const int y = yo * sh - ph + i, xx = xo * sw - pw + j;
+      if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[((size_t)c * H + y) * W + xx];
+    }
+    cra5_store_split(cols_s + tok * 2 * Kp, k, v);
+  }
+}
+
+// out[co][y][x] = bias[co] + sum_{i, j} cols[(yi, xi)][(co kh + i) kw + j],  y = yi s - p + i, x = xi s - p + j
+__global__ __launch_bounds__(256) void deconv_col2im_kernel(const float *__restrict__ cols, const float *__restrict__ bias,
+                                                            float *__restrict__ out, int Cout, int Hi, int Wi, int kh,
+                                                            int kw, int sh, int sw, int ph, int pw, int Ho, int Wo,
+                                                            int ldn) {
+  const size_t total = (size_t)Cout * Ho * Wo;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int xo = (int)(e % Wo);
+    const size_t t = e / Wo;
+    const int yo = (int)(t % Ho), co = (int)(t / Ho);
+    float acc = bias ? bias[co] : 0.f;
+    for (int i = (yo + ph) % sh; i < kh; i += sh) {
+      const int yi = (yo + ph - i) / sh;
+      if (yo + ph - i < 0 || yi >= Hi) continue;
+      for (int j = (xo + pw) % sw; j < kw; j += sw) {
+        const int xi = (xo + pw - j) / sw;
+        if (xo + pw - j < 0 || xi >= Wi) continue;
+        acc += cols[(size_t)(yi * Wi + xi) * ldn + (co * kh + i) * kw + j];
+      }
+    }
+    out[e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void unary_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n, int op,
+                                                    float slope) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[e];
+    y[e] = (op == 1) ? __builtin_fabsf(v) : ((v >= 0.f) ? v : v * slope);   // 0: relu / leaky relu, 1: abs
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // GaussianConditional (entropy_models.py:645-685).  Phi(u) = 0.5 * erfc(-u / sqrt 2).
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float phi(float u) { return 0.5f * erfcf(-0.70710678118654752440f * u); }
@@ -619,6 +676,33 @@ int cra5_pixel_shuffle_f32(const float *lin, float *out, int Hz, int Wz, int p1,
   const size_t total = (size_t)Cout * Hz * p1 * Wz * p2;
   hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, lin, out, Hz, Wz,
                      p1, p2, Cout);
+  return (int)hipGetLastError();
+}
+
+int cra5_conv_im2col_f32(const float *x, uint16_t *cols_split, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
+                         int pw, int Ho, int Wo, int ldk, void *stream) {
+  if (!x || !cols_split || C <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0) return CRA5_ERR_ARG;
+  if (ldk < C * kh * kw || (ldk % 32)) return CRA5_ERR_ARG;
+  if (Ho != (H + 2 * ph - kh) / sh + 1 || Wo != (W + 2 * pw - kw) / sw + 1) return CRA5_ERR_ARG;
+  const size_t total = (size_t)Ho * Wo * ldk;
+  hipLaunchKernelGGL(conv_im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, cols_split, C, H, W,
+                     kh, kw, sh, sw, ph, pw, Ho, Wo, ldk);
+  return (int)hipGetLastError();
+}
+
+int cra5_deconv_col2im_f32(const float *cols, const float *bias, float *out, int Cout, int Hi, int Wi, int kh, int kw,
+                           int sh, int sw, int ph, int pw, int Ho, int Wo, int ldn, void *stream) {
+  if (!cols || !out || Cout <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0) return CRA5_ERR_ARG;
+  if (ldn < Cout * kh * kw || Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0) return CRA5_ERR_ARG;
+  const size_t total = (size_t)Cout * Ho * Wo;
+  hipLaunchKernelGGL(deconv_col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, cols, bias, out, Cout,
+                     Hi, Wi, kh, kw, sh, sw, ph, pw, Ho, Wo, ldn);
+  return (int)hipGetLastError();
+}
+
+int cra5_unary_f32(const float *x, float *y, size_t n, int op, float slope, void *stream) {
+  if (!x || !y || n == 0 || op < 0 || op > 1) return CRA5_ERR_ARG;
+  hipLaunchKernelGGL(unary_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, op, slope);
   return (int)hipGetLastError();
 }
 

@@ -399,6 +399,46 @@ def pixel_shuffle(lin, Hz, Wz, p1, p2, out=None):
     return out
 
 
+def conv2d(x, w_split, bias, k, stride, act=None):
+    """nn.Conv2d(k, stride, padding=k//2) on one image x [C, H, W] (models/utils.py:128-135): padded patch
+    gather -> split-f16 GEMM (+ bias) -> [Cout, Ho, Wo].  w_split: SplitMat of weight.reshape(Cout, -1)."""
+    _dev(x, bias)
+    C, H, W = x.shape
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
+    cols = SplitMat.empty(Ho * Wo, C * k * k, x.device)
+    check(lib().cra5_conv_im2col_f32(_p(x.contiguous()), _p(cols.data), C, H, W, k, k, stride, stride, p, p, Ho, Wo,
+                                     cols.Kp, _stream()), "cra5_conv_im2col_f32")
+    tok = gemm_nt_split(cols, w_split, bias=bias)                 # [Ho*Wo, Cout]
+    out = transpose(tok).view(w_split.rows, Ho, Wo)
+    return unary(out, act) if act else out
+
+
+def conv_transpose2d(x, w_split, bias, cout, k, stride):
+    """nn.ConvTranspose2d(k, stride, padding=k//2, output_padding=stride-1) on x [Cin, Hi, Wi]
+    (models/utils.py:138-146).  w_split: SplitMat of weight.reshape(Cin, cout*k*k).t()."""
+    _dev(x, bias)
+    Cin, Hi, Wi = x.shape
+    p = k // 2
+    Ho, Wo = (Hi - 1) * stride - 2 * p + k + (stride - 1), (Wi - 1) * stride - 2 * p + k + (stride - 1)
+    tok = split_f16(transpose(x.reshape(Cin, Hi * Wi).contiguous()))          # [Hi*Wi, Cin]
+    cols = gemm_nt_split(tok, w_split)                                        # [Hi*Wi, cout*k*k]
+    out = torch.empty((cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    check(lib().cra5_deconv_col2im_f32(_p(cols), _p(bias), _p(out), cout, Hi, Wi, k, k, stride, stride, p, p, Ho, Wo,
+                                       _row_stride(cols), _stream()), "cra5_deconv_col2im_f32")
+    return out
+
+
+def unary(x, op, slope=0.0):
+    """op: 'relu' | 'leaky_relu' (slope) | 'abs'."""
+    _dev(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    code, sl = {"relu": (0, 0.0), "leaky_relu": (0, slope or 0.01), "abs": (1, 0.0)}[op]
+    check(lib().cra5_unary_f32(_p(x), _p(y), x.numel(), code, float(sl), _stream()), "cra5_unary_f32")
+    return y
+
+
 def gaussian_conditional(scales, means, scale_table, y=None, sym_in=None, want=("idx", "sym", "y_hat"),
                          scale_bound=0.11, lik_bound=1e-9):
     """Fused GC kernel. Returns dict with the requested outputs (flat views shaped like `means`)."""

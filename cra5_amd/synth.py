@@ -50,6 +50,14 @@ def synth_tensor(key, shape, seed=0):
             hi = med + 4.0 * (1 + 0.3 * rng.random(C).astype(np.float32))
             return torch.from_numpy(np.stack([lo, med, hi], -1).reshape(C, 1, 3))
         return None
+    if leaf in ("beta", "gamma") and (".beta_reparam" not in key and ".gamma_reparam" not in key):
+        # GDN parameters (layers/gdn.py:41-74) in their re-parametrised form sqrt(v + pedestal)
+        ped = np.float32(2.0 ** -36)
+        if leaf == "beta":
+            v = 1.0 + 0.5 * rng.random(size=shape, dtype=np.float32)
+        else:
+            v = 0.1 * np.eye(shape[0], dtype=np.float32) + 0.02 * np.abs(rng.standard_normal(size=shape, dtype=np.float32))
+        return torch.from_numpy(np.sqrt(np.maximum(v + ped, ped)).astype(np.float32))
     if leaf == "pos_embed":
         return _randn(rng, shape, 0.2)
     if ".norm" in key and leaf == "weight" and len(shape) == 1:
@@ -69,6 +77,8 @@ def synth_tensor(key, shape, seed=0):
             gain = 6.0
         if key == "h_s.final.weight":
             gain = 2.0
+        if key in ("g_a.6.weight", "h_a.4.weight"):   # CNN zoo: last analysis convs (latents of O(few))
+            gain = 4.0
         return _randn(rng, shape, gain / np.sqrt(fan_in))
     return None
 

@@ -14,10 +14,15 @@ import torch
 
 from .vaeformer import VAEformer
 
-__all__ = ["vaeformer_pretrained", "load_pretrained", "rename_key", "model_architectures", "cfgs"]
+from . import cnn as _cnn
 
-model_architectures = {"vaeformer-pretrained": VAEformer}
-cfgs = {"vaeformer-pretrained": {268: (268,), 159: (159,)}}
+__all__ = ["vaeformer_pretrained", "bmshj2018_factorized", "bmshj2018_hyperprior", "mbt2018_mean", "load_pretrained",
+           "rename_key", "model_architectures", "cfgs"]
+
+# zoo/image.py:56-62 / :202-245 (the autoregressive `mbt2018` and the ReLU variant are not built)
+model_architectures = {"vaeformer-pretrained": VAEformer, "bmshj2018-factorized": _cnn.FactorizedPrior,
+                       "bmshj2018-hyperprior": _cnn.ScaleHyperprior, "mbt2018-mean": _cnn.MeanScaleHyperprior}
+cfgs = dict({"vaeformer-pretrained": {268: (268,), 159: (159,)}}, **_cnn.CNN_CFGS)
 _CKPT_NAMES = {268: "cra5_268v_300k.pth"}  # zoo/image.py:69-75
 
 
@@ -76,3 +81,19 @@ def vaeformer_pretrained(quality, metric="mse", pretrained=False, progress=True,
     if quality < 1 or quality > 999:
         raise ValueError(f'Invalid quality "{quality}", should be between (1, 999)')
     return _load_model("vaeformer-pretrained", metric, quality, pretrained, progress, **kwargs)
+
+
+def _cnn_entry(architecture):
+    def entry(quality, metric="mse", pretrained=False, progress=True, **kwargs):
+        if metric not in ("mse", "ms-ssim"):
+            raise ValueError(f'Invalid metric "{metric}"')
+        if quality < 1 or quality > 8:
+            raise ValueError(f'Invalid quality "{quality}", should be between (1, 8)')
+        return _load_model(architecture, metric, quality, pretrained, progress, **kwargs)
+    entry.__doc__ = f"zoo/image.py entry point of `{architecture}` (google.py:64-508) on the HIP kernels (cra5_amd/cnn.py)."
+    return entry
+
+
+bmshj2018_factorized = _cnn_entry("bmshj2018-factorized")     # zoo/image.py:326-348
+bmshj2018_hyperprior = _cnn_entry("bmshj2018-hyperprior")     # zoo/image.py:376-398
+mbt2018_mean = _cnn_entry("mbt2018-mean")                     # zoo/image.py:401-423

@@ -222,6 +222,18 @@ int cra5_transpose_f32(const float *in, int ld_in, float *out, int ld_out, int r
 int cra5_pixel_shuffle_f32(const float *lin, float *out, int Hz, int Wz, int p1, int p2,
                            int Cout, void *stream);
 
+/* CNN zoo (bmshj2018-factorized / -hyperprior, mbt2018-mean: cra5/models/compressai/models/google.py:64-508;
+ * conv / deconv of models/utils.py:128-147).  Conv2d(k, s, padding p): zero-padded patch gather into the
+ * split-f16 GEMM operand, cols_split [Ho*Wo][2*ldk], column (c*kh + i)*kw + j, pad columns zero.
+ * ConvTranspose2d(k, s, padding p, output_padding): cols = in^T . W (GEMM, fp32 [Hi*Wi][ldn], column
+ * (co*kh + i)*kw + j), then out[co][y][x] = bias[co] + sum of the contributions with y = yi*s - p + i. */
+int cra5_conv_im2col_f32(const float *x, uint16_t *cols_split, int C, int H, int W, int kh, int kw, int sh, int sw,
+                         int ph, int pw, int Ho, int Wo, int ldk, void *stream);
+int cra5_deconv_col2im_f32(const float *cols, const float *bias, float *out, int Cout, int Hi, int Wi, int kh, int kw,
+                           int sh, int sw, int ph, int pw, int Ho, int Wo, int ldn, void *stream);
+/* y = relu(x) / leaky_relu(x, slope) (op 0; slope 0 = ReLU) or |x| (op 1); x == y allowed. */
+int cra5_unary_f32(const float *x, float *y, size_t n, int op, float slope, void *stream);
+
 /* ============================ device: entropy models ========================== */
 
 /* GaussianConditional, eval mode (entropy_models.py:645-685, 155-201):

@@ -17,6 +17,9 @@ dumps small input/output fixtures (data only) next to this script:
                         variables (reference `VAEformer(0, ddconfig=... in_chans=159 ...)`,
                         the ddconfig route of vaeformer.py:78-143; `VAEformer(159)` itself
                         crashes in the reference), encode_latent + decode_latent
+  cnn_zoo.npz           (--stage cnn) bmshj2018-factorized / -hyperprior, mbt2018-mean at N=32, M=48 on a
+                        3 x 128 x 192 image: y, z, h_s, x_hat (forward, round trip, synthetic y_hat),
+                        likelihood bits, rANS strings
   era5_stats_ref.npz    (--stage stats) the reference's own 268-long mean / std vectors
                         (cra5_api.get_mean_std, cra5_api.py:243-261) and channel -> vname map
                         (:228-241), computed by the reference's code on its own JSONs/config
@@ -314,6 +317,46 @@ def stage_full159():
     print("full159 done")
 
 
+def stage_cnn():
+    """the reference's CNN zoo classes (models/google.py:64-508) at N=32, M=48 on one
+    3 x 128 x 192 image, synthetic weights from cra5_amd/synth.py -> cnn_zoo.npz."""
+    from cra5.models.compressai.models.google import FactorizedPrior, MeanScaleHyperprior, ScaleHyperprior
+    N, M = 32, 48
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(1, 3, 128, 192, generator=g)
+    o, keys = {"x": x.numpy()}, {}
+    for name, cls in (("factorized", FactorizedPrior), ("hyperprior", ScaleHyperprior), ("meanscale", MeanScaleHyperprior)):
+        net = cls(N, M).eval()
+        shapes = load_synth(net, seed=11)
+        keys[name] = {k: list(v.shape) for k, v in net.state_dict().items()}
+        y = net.g_a(x)
+        o[f"{name}_y"] = y.numpy()
+        fw = net(x)
+        o[f"{name}_xhat_fw"] = sub(fw["x_hat"], 5)
+        for k, v in fw["likelihoods"].items():
+            o[f"{name}_bits_{k}"] = np.array([float((-torch.log2(v)).sum())])
+        gy = torch.Generator().manual_seed(5)
+        y_hat = torch.round(3.0 * torch.randn(y.shape, generator=gy))
+        o[f"{name}_xhat_synth"] = sub(net.g_s(y_hat), 5)                 # decoder on a regenerable y_hat
+        out = net.compress(x)
+        rec = net.decompress(out["strings"], out["shape"])
+        o[f"{name}_xhat_rt"] = sub(rec["x_hat"], 5)
+        for i, ss in enumerate(out["strings"]):
+            o[f"{name}_string{i}"] = np.frombuffer(ss[0], dtype=np.uint8)
+        o[f"{name}_shape"] = np.array(list(out["shape"]))
+        if name != "factorized":
+            z = net.h_a(y if name == "meanscale" else torch.abs(y))
+            o[f"{name}_z"] = z.numpy()
+            z_hat, _ = net.entropy_bottleneck(z)
+            p = net.h_s(z_hat)
+            o[f"{name}_hs"] = p.numpy()
+    np.savez_compressed(os.path.join(HERE, "cnn_zoo.npz"), **o)
+    sk = json.load(open(os.path.join(HERE, "state_keys.json")))
+    sk["cnn"] = keys
+    json.dump(sk, open(os.path.join(HERE, "state_keys.json"), "w"))
+    print("cnn done")
+
+
 def stage_stats():
     """The reference's cra5_api.get_mean_std / channel_vname_mapping run on the reference's own
     config + JSON files (the methods only read self.cfg / self.level_mapping, so they are called
@@ -392,4 +435,5 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for s in a.stage:
         dict(small=stage_small, thin=stage_thin, full=stage_full, full159=stage_full159, stats=stage_stats,
+             cnn=stage_cnn,
              thin64=lambda: stage_fp64("thin"), full64=lambda: stage_fp64("full"))[s]()

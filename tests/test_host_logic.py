@@ -5,6 +5,8 @@ import json
 import struct
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -207,6 +209,21 @@ def test_netcdf_ingest_channel_order(tmp_path):
         (d / "2024-06-01T01:00:00_single.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
         with pytest.raises(RuntimeError, match="NetCDF-4"):
             api.read_data_from_nc("2024-06-01T01:00:00")
+
+
+def test_api_visualisation_helpers(tmp_path):
+    """show_image / show_latent (cra5_api.py:273-341): figure files at the reference's paths."""
+    import numpy as np
+    from cra5_amd.api import cra5_api
+    api = cra5_api(local_root=str(tmp_path), device="cpu", weights=VAEformer(0, **synth.thin_model_kwargs()))
+    rng = np.random.default_rng(0)
+    ori = rng.standard_normal((268, 20, 40)).astype(np.float32)
+    rec = ori + 0.01 * rng.standard_normal(ori.shape).astype(np.float32)
+    ts = "2024-06-01T00:00:00"
+    p = api.show_image(torch.from_numpy(rec).unsqueeze(0), ts, show_variables=['z_500', 't_850'], data=ori)
+    assert p == f"{tmp_path}/CRA5_vis/2024/{ts}_reconstruction.png" and os.path.getsize(p) > 1000
+    q = api.show_latent(rng.standard_normal((1, 256, 72, 144)).astype(np.float32), ts, save_path=str(tmp_path / "v"))
+    assert q.endswith(f"v/{ts}_latent.png") and os.path.getsize(q) > 1000
 
 
 def test_install_dropin():
