@@ -616,6 +616,16 @@ extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t 
   return gemm_dispatch(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
 }
 
+// Fixed-tile entry for the hyper-prior path (csrc/hyper.hip): 64 x 64 or 128 x 128 tiles chosen by the CALLER,
+// never by CRA5_GEMM_TILE - the encode and the decode side must run the same kernel (bit-identical h_s).
+extern "C" __attribute__((visibility("hidden"))) int cra5_internal_gemm_split_tile(
+    const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C, int ldc, unsigned short *Cs,
+    long ldcs, const float *bias, const float *res, int ldr, int M, int N, int Kp, float wscale_inv, int flags,
+    int tile, hipStream_t st) {
+  if (tile == 64) return launch<2, 2, 1, 1, false>(A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+  return launch<2, 2, 2, 2, false>(A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+}
+
 extern "C" size_t cra5_gemm_sk_workspace_bytes(void) {
   return SK_COUNTER_BYTES + (size_t)2 * cu_count() * SK_BM * SK_BN * sizeof(float);
 }

@@ -29,6 +29,8 @@
 // decoder bit-identical CDF indexes (a flipped index desynchronises the rANS stream).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/cra5_amd.h"
 #include "split.h"
@@ -362,6 +364,11 @@ __global__ __launch_bounds__(NW * 64) void hyper_attention_kernel(const float *_
 
 }  // namespace
 
+extern "C" int cra5_internal_gemm_split_tile(const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C,
+                                             int ldc, unsigned short *Cs, long ldcs, const float *bias,
+                                             const float *res, int ldr, int M, int N, int Kp, float wscale_inv,
+                                             int flags, int tile, hipStream_t st);
+
 extern "C" int cra5_small_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw_kp, float *C, int ldc,
                                         uint16_t *C_split, int ldc_split_kp, const float *bias, const float *res,
                                         int ldr, int M, int N, int Kp, float wscale_inv, int flags, int ps_Hz, int ps_Wz,
@@ -389,7 +396,30 @@ extern "C" int cra5_small_gemm_nt_split(const uint16_t *A, int lda_kp, const uin
   return launch_small<TN, KS, D, false>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, ps, st)
   const long tiles1 = (long)((M + 31) / 32) * ((N + 31) / 32);
   const int nk = Kp / 32;
-  // few tiles and a long reduction: split the k-steps over the waves of a block
+  // CRA5_HY_GEMM = "TN KS" forces an instantiation (tools/hyper_gemm_sweep.py)
+  static const int forced = [] {
+    const char *e = getenv("CRA5_HY_GEMM");
+    int tn = 0, ks = 0;
+    if (e && sscanf(e, "%d %d", &tn, &ks) == 2) return tn * 100 + ks;
+    return 0;
+  }();
+  switch (forced) {
+    case 101: HY_GO(1, 1, 4);
+    case 102: HY_GO(1, 2, 4);
+    case 104: HY_GO(1, 4, 2);
+    case 108: HY_GO(1, 8, 2);
+    case 201: HY_GO(2, 1, 3);
+    case 202: HY_GO(2, 2, 2);
+    case 204: HY_GO(2, 4, 2);
+    case 401: HY_GO(4, 1, 2);
+    default: break;
+  }
+  // Measured on MI355X.  Warm micro-benchmark per shape (tools/hyper_gemm_sweep.sh, kernel us, this kernel vs the
+  // LDS-tiled engine at a fixed 64 / 128 tile): 648x360x4096 34 vs 65, 648x360x1440 15.1 vs 16.2, 648x1080x360
+  // 13.2 vs 8.6, 648x1440x360 16.1 vs 9.1, 648x8192x360 60 vs 26.  IN SITU (every GEMM of h_s meets weights that
+  // are cold in L2; tools/hyper_bench.py) the picture flips for the short reductions too - h_s 436 us with this
+  // kernel everywhere vs 507 us with the 64-tile engine forwarded for K = 360: four k-steps of loads in flight
+  // per wave ride out the misses that a two-stage LDS pipeline stalls on.  So: this kernel for every shape.
   if (nk >= 96) HY_GO(1, 8, 2);
   if (nk >= 32 && tiles1 <= 1024) HY_GO(1, 4, 2);
   if (tiles1 > 4096) HY_GO(4, 1, 2);
