@@ -301,7 +301,9 @@ def main():
         x2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); PMC collection needs its
         own profiler runs, so bench.py reports the committed measurement, not a live one."""
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+            t = json.load(open(latest))
             return t["gemm_nt_split"]["avg_bytes_per_launch"]
         except Exception:  # noqa: BLE001
             return None
@@ -320,7 +322,7 @@ def main():
             out["roofline"] = {"kernel": "gemm_nt_split_kernel<2,4,{3|4},2> (192x256 / 256x256 tiles)", "bound": "mfma", "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": measured_traffic(),
                                "traffic_note": "bytes/launch at the L2<->fabric boundary (Infinity-Cache hits "
-                                               "included), profiles/r01_traffic.json; algorithmic minimum "
+                                               "included), newest profiles/r*_traffic.json; algorithmic minimum "
                                                "A + W + C = 55-230 MB/launch",
                                "peak_note": "dense f16 MFMA peak 2500 TF / %d MFMA(s) per product; a pure MFMA loop on this "
                                             "chip sustains 1930-1980 TF at the 1.8-1.9 GHz it clocks under that load "
