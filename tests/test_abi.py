@@ -38,6 +38,14 @@ def test_argument_validation_without_gpu():
     assert L.cra5_split_f16(None, 0, None, 1, 1, 32, 1.0, None) == -7
     assert L.cra5_window_attention_split(None, 0, None, None, None, 0, 64, 1, 1, 1, 1, 1, 1.0, 0, None) == -7
     assert L.cra5_pmf_to_quantized_cdf(None, 0, 16, None) == -7
+    assert L.cra5_small_gemm_nt_split(None, 32, None, 32, None, 0, None, 0, None, None, 0, 1, 1, 32, 1.0, 0, 0, 0, 0, 0,
+                                      None) == -7
+    assert L.cra5_hyper_attention_f32(None, None, None, 0, 1, 72, 1, 1.0, None) == -7
+    assert L.cra5_conv_im2col_f32(None, None, 1, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 32, None) == -7
+    assert L.cra5_deconv_col2im_f32(None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, None) == -7
+    assert L.cra5_unary_f32(None, None, 1, 0, 0.0, None) == -7
+    assert L.cra5_debug_range_counts(None, 0) == -8          # not compiled into the release flavour
+    assert L.cra5_gemm_sk_workspace_bytes() > 2 * 256 * 256 * 4
 
 
 def test_no_cuda_shims_or_dual_paths_in_sources():
