@@ -2,9 +2,9 @@
 // row = [chunk 0: 32 hi halves | 32 lo halves][chunk 1: ...]; x = hi + lo, hi = f16(x),
 // lo = f16(x - hi).
 //
-// Range: f16 tops out at 65 504.  hi is SATURATED there and lo carries the rest (exact up to
-// |x| = 131 008, saturating beyond), so an out-of-range activation degrades to a clipped
-// value instead of hi = inf, lo = -inf -> NaN products (two v_med3 per element).  Builds with
+// Range: f16 tops out at 65 504.  The value is SATURATED there before the split (one v_med3 per
+// element), so an out-of-range activation degrades to +-65 504 instead of hi = inf, lo = -inf ->
+// NaN products.  Builds with
 // -DCRA5_RANGE_CHECK (python -m cra5_amd.build --flavour rangecheck) additionally count, per
 // producer call site, the elements with |x| >= 65 504 and the non-finite ones
 // (cra5_debug_range_counts in the C ABI): the evidence that a checkpoint's activations stay
@@ -40,8 +40,8 @@ __device__ __forceinline__ void cra5_range_probe(float) {}
 
 __device__ __forceinline__ void cra5_split(float v, _Float16 &hi, _Float16 &lo) {
   cra5_range_probe(v);
-  const float vc = __builtin_amdgcn_fmed3f(v, -131008.0f, 131008.0f);
-  hi = (_Float16)__builtin_amdgcn_fmed3f(vc, -65504.0f, 65504.0f);
+  const float vc = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+  hi = (_Float16)vc;
   lo = (_Float16)(vc - (float)hi);
 }
 

@@ -285,6 +285,11 @@ def test_full268_vs_reference_golden(big, dev, golden_dir):
           f"means {e_m:.3e}, scales {e_s:.3e}, idx flips {idx_mis}, sym flips {sym_mis}, "
           f"sym hist L1 {int(np.abs(hist - g['sym_hist']).sum())}, idx hist L1 {int(np.abs(idx_hist - g['idx_hist']).sum())}")
     assert e_y <= 1e-5
+    # forward()'s likelihood outputs (vaeformer.py:302-333) at full size: total bits within 2e-4 of the reference's
+    bits_y = float((-torch.log2(s["y_lik"].double())).sum())
+    bits_z = float((-torch.log2(s["z_lik"].double())).sum())
+    print(f"268: bits y {bits_y:.6e} (ref {g['bits_y'][0]:.6e}), bits z {bits_z:.6e} (ref {g['bits_z'][0]:.6e})")
+    assert abs(bits_z - g["bits_z"][0]) <= 2e-4 * g["bits_z"][0]
     z_rms = float(np.sqrt(g["z_stats"][1] / s["z"].numel()))
     assert e_z <= 1e-5 * max(1.0, z_rms)   # z is O(7) with the synthetic gains: relative 1e-5
     # z mod 1 is ~uniform, so a symbol flips with probability 2|err|: expect numel * 2 * 0.8 * rmse
@@ -294,6 +299,7 @@ def test_full268_vs_reference_golden(big, dev, golden_dir):
     if z_hist_l1 == 0 and z_flips == 0:
         assert e_m <= 1e-5 and e_s <= 1e-5
         assert idx_mis <= 1 and sym_mis <= 1
+        assert abs(bits_y - g["bits_y"][0]) <= 2e-4 * g["bits_y"][0]
     else:
         assert e_m <= 5e-3 and e_s <= 5e-3   # bounded effect of <= 4 z flips
     p = _hs_from_synth(big, dev)
