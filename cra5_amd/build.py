@@ -26,8 +26,14 @@ LIB = os.path.join(HERE, "libcra5_amd.so")
 SOURCES = ["host_entropy.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "attention_f32.hip", "attention_split_f16.hip",
            "elementwise.hip", "hyper.hip", "runtime.hip"]
 SOURCES = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-HEADERS = [os.path.join(ROOT, "include", "cra5_amd.h"), os.path.join(CSRC, "split.h")]
+HEADERS = [os.path.join(ROOT, "include", "cra5_amd.h"), os.path.join(CSRC, "split.h"),
+           os.path.join(CSRC, "gemm_split_epilogue.inc")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# per-file flags.  gemm_split_f16.hip: the epilogue's row-block loop must unroll FULLY in every instantiation (a
+# dynamically indexed accumulator array lives in scratch); the 128 x 128-per-wave one exceeds clang's default
+# 16 K-instruction budget for `#pragma unroll`.
+EXTRA = {"gemm_split_f16.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
 
 FLAVOURS = {
     "release": dict(host=["-O3"], dev=["-O3"], link=[]),
@@ -69,7 +75,8 @@ def build(force=False, verbose=False, flavour="release"):
             if s.endswith(".cpp"):
                 cmd = [HIPCC, "-x", "c++", "-std=c++17", "-fPIC"] + fl["host"] + ["-c", src, "-o", obj]
             else:
-                cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fPIC"] + fl["dev"] + ["-c", src, "-o", obj]
+                cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fPIC"] + fl["dev"] + EXTRA.get(s, []) + \
+                      ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

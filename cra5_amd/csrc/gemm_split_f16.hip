@@ -344,123 +344,11 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   // MODE 0: accumulators -> outputs.  MODE 1 (split tile): accumulators -> this segment's partial tile in the
   // workspace, raw fp32 [BM][BN] (published by the agent-scope release of the arrival counter).  MODE 2 (last
   // arriver of a split tile): sum of ALL its partial tiles in k order (our own re-read, so the association
-  // does not depend on who arrived last) -> outputs.  Two instantiations touch `acc`, MODE 2 does not:
-  // the 128 accumulator registers are dead while partial tiles stream through.
-  auto epilogue = [&](auto mode_tag) __attribute__((always_inline)) {
-    constexpr int MODE = decltype(mode_tag)::value;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mrow0 = m0 + (wm * TM + i) * 32;
-      if (mrow0 >= M) break;               // wave-uniform
-      float4 v4[32 / RPI];
-      if (MODE != 2) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = acc[i][j][r];
-            if (LONGK) v += master[i][j][r];
-            stg[(4 * h + (r & 3) + 8 * (r >> 2)) * LDW + j * 32 + l31] = v;
-          }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int p = 0; p < 32 / RPI; ++p) v4[p] = *reinterpret_cast<const float4 *>(stg + (p * RPI + er) * LDW + ec);
-        __builtin_amdgcn_wave_barrier();
-      } else {
-#pragma unroll
-        for (int p = 0; p < 32 / RPI; ++p) v4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pp = p_first; pp <= p_last; ++pp) {
-          const long ps = (long)pp * sk_total / P;
-          const int slot = 2 * pp + ((ps < sk_t0) ? 1 : 0);   // range began in an earlier tile: its hi segment
-          const float *wsp = sk.ws + (size_t)slot * TILE_F + (size_t)((wm * TM + i) * 32 + er) * BN + wn * COLS + ec;
-#pragma unroll
-          for (int p = 0; p < 32 / RPI; ++p) {
-            const float4 t4 = *reinterpret_cast<const float4 *>(wsp + (size_t)p * RPI * BN);
-            v4[p].x += t4.x;
-            v4[p].y += t4.y;
-            v4[p].z += t4.z;
-            v4[p].w += t4.w;
-          }
-        }
-      }
-      if (MODE == 1) {
-        float *wsp = sk.ws + (size_t)my_slot * TILE_F + (size_t)((wm * TM + i) * 32 + er) * BN + wn * COLS + ec;
-#pragma unroll
-        for (int p = 0; p < 32 / RPI; ++p) *reinterpret_cast<float4 *>(wsp + (size_t)p * RPI * BN) = v4[p];
-        continue;
-      }
-      float4 r4[32 / RPI];
-      if (has_res) {
-#pragma unroll
-        for (int p = 0; p < 32 / RPI; ++p) {
-          const int m = mrow0 + p * RPI + er;
-          r4[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (m < M && nw < N) {
-            const float *rp = res + (size_t)m * ldr + nw;
-            if (vecR && nw + 3 < N) {
-              r4[p] = *reinterpret_cast<const float4 *>(rp);
-            } else {
-              r4[p].x = rp[0];
-              if (nw + 1 < N) r4[p].y = rp[1];
-              if (nw + 2 < N) r4[p].z = rp[2];
-              if (nw + 3 < N) r4[p].w = rp[3];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < 32 / RPI; ++p) {
-        const int m = mrow0 + p * RPI + er;
-        if (m >= M) continue;
-        if (nw >= N) {
-          // pad columns N .. ldcs/2 of the split output are the zero K padding of the consumer
-          if (Cs && nw < (int)(ldcs >> 1)) {
-            unsigned short *sp = Cs + (size_t)m * ldcs + (nw >> 5) * 64 + (nw & 31);
-            *reinterpret_cast<uint2 *>(sp) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2 *>(sp + 32) = make_uint2(0u, 0u);
-          }
-          continue;
-        }
-        float o[4] = {v4[p].x, v4[p].y, v4[p].z, v4[p].w};
-        const float rr[4] = {r4[p].x, r4[p].y, r4[p].z, r4[p].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float v = o[c] * wscale_inv + bv[c];
-          if (do_gelu) v = gelu_erf(v);
-          if (has_res) v += rr[c];
-          o[c] = (nw + c < N) ? v : 0.f;
-        }
-        if (C) {
-          float *cp = C + (size_t)m * ldc + nw;
-          if (vecC && nw + 3 < N) {
-            *reinterpret_cast<float4 *>(cp) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-            cp[0] = o[0];
-            if (nw + 1 < N) cp[1] = o[1];
-            if (nw + 2 < N) cp[2] = o[2];
-            if (nw + 3 < N) cp[3] = o[3];
-          }
-        }
-        if (Cs) {
-          // split layout: 128-byte chunk per 32 columns = [32 hi | 32 lo]; 4 columns -> 8 B + 8 B.
-          // Columns >= N inside the group are written as zero (they are K padding of the consumer).
-          unsigned short hi[4], lo[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            _Float16 hh, ll;
-            cra5_split(o[c], hh, ll);
-            hi[c] = __builtin_bit_cast(unsigned short, hh);
-            lo[c] = __builtin_bit_cast(unsigned short, ll);
-          }
-          unsigned short *sp = Cs + (size_t)m * ldcs + (nw >> 5) * 64 + (nw & 31);
-          *reinterpret_cast<uint2 *>(sp) = make_uint2(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16));
-          *reinterpret_cast<uint2 *>(sp + 32) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
-        }
-      }
-    }
-  };
+  // does not depend on who arrived last) -> outputs.  (gemm_split_epilogue.inc, included once per mode.)
   if (SK && (ka != 0 || kb != nk_all)) {
-    epilogue(std::integral_constant<int, 1>{});
+#define EPI_MODE 1
+#include "gemm_split_epilogue.inc"
+#undef EPI_MODE
     // contributors of this tile: work-groups whose ranges meet [t nk, (t+1) nk)
     const int t_sk = tile - sk.dp_rounds * P;
     sk_t0 = (long)t_sk * nk_all;
@@ -483,9 +371,15 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
       sk_last = last;
     }
     __syncthreads();
-    if (sk_last) epilogue(std::integral_constant<int, 2>{});
+    if (sk_last) {
+#define EPI_MODE 2
+#include "gemm_split_epilogue.inc"
+#undef EPI_MODE
+    }
   } else {
-    epilogue(std::integral_constant<int, 0>{});
+#define EPI_MODE 0
+#include "gemm_split_epilogue.inc"
+#undef EPI_MODE
   }
   if (SK) __syncthreads();   // the next item's LDS-DMA overwrites the epilogue scratch
   }  // item loop
@@ -579,6 +473,9 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
     else if (M >= 1024 && N >= 512) tile = 192;
     else tile = 128;
   }
+  // (a 4-wave 256 x 256 instantiation - one wave per SIMD, 128 x 128 per wave, 256 accumulator AGPRs, a third less
+  // LDS fragment traffic per MFMA - compiles spill-free but measured 4-5 % SLOWER with hipcc's schedule: qkv 197 vs
+  // 190 us, un-embed 1922 vs 1832; a single wave per SIMD needs a hand-placed MFMA / ds_read / LDS-DMA interleave)
   if (tile == 64) CRA5_GO(2, 2, 1, 1, false);
   if (tile == 192) CRA5_GO(2, 4, 3, 2, false);   // 192 x 256, 8 waves (2 x 4), 3 x 2 sub-tiles per wave
   if (tile == 256) CRA5_GO(2, 4, 4, 2, false);   // 256 x 256, 8 waves (2 x 4), 4 x 2 sub-tiles per wave
