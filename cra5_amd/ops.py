@@ -95,8 +95,8 @@ def _p(t):
 
 
 def _row_stride(t):
-    assert t.dim() == 2 and t.stride(1) == 1, "expected a 2-D tensor with unit inner stride"
-    return t.stride(0)
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), "expected a 2-D tensor with unit inner stride"
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
 def gemm_nt(a, w, bias=None, res=None, gelu=False, out=None):

@@ -8,15 +8,83 @@ dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
-n_gemm = n_att = n_ln = 0
-worst = {"gemm": 0.0, "att": 0.0, "ln": 0.0}
+n_gemm = n_att = n_ln = n_small = n_hatt = n_conv = 0
+worst = {"gemm": 0.0, "att": 0.0, "ln": 0.0, "small": 0.0, "hatt": 0.0, "conv": 0.0}
+sk_ws = ops.gemm_sk_workspace(dev)
 def rel(a, b):
     """rmse / (rms(ref) + 0.05): relative for O(1) data, absolute (the split format's 2^-25 floor, see the
     header of csrc/gemm_split_f16.hip) when the reference itself is tiny."""
     b = b.double().cpu(); a = a.double().cpu()
     return float(torch.sqrt(torch.mean((a - b) ** 2)) / (float(torch.sqrt(torch.mean(b ** 2))) + 0.05))
 while time.time() < t_end:
-    kind = rng.integers(0, 10)
+    kind = rng.integers(0, 16)
+    if kind >= 10:
+        sub = int(kind) - 10
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        if sub < 3:      # small-M GEMM of the hyper-prior path: all dispatch branches, epilogues, pad columns
+            M = int(rng.choice([1, 17, 32, 33, 100, 162, 648, 700, 1500]))
+            N = int(rng.choice([1, 8, 31, 36, 77, 256, 360, 1080, 1440, 2500, 8192]))
+            K = int(rng.choice([1, 31, 32, 52, 144, 256, 360, 1000, 1440, 4096]))
+            if M * N * K > 8e9: continue
+            a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) * 0.05
+            bias = torch.randn(N, generator=g) if rng.random() < 0.7 else None
+            res = torch.randn(M, N, generator=g) if rng.random() < 0.5 else None
+            gelu = bool(rng.random() < 0.4)
+            ref = a.double() @ w.double().t()
+            if bias is not None: ref = ref + bias.double()
+            if gelu: ref = torch.nn.functional.gelu(ref)
+            if res is not None: ref = ref + res.double()
+            sa, sw = ops.split_f16(a.to(dev)), ops.split_f16(w.to(dev), "auto")
+            out_s = ops.SplitMat.empty(M, N, dev); out_s.data.fill_(0x7e00)
+            out = ops.small_gemm_nt_split(sa, sw, bias=None if bias is None else bias.to(dev),
+                                          res=None if res is None else res.to(dev), gelu=gelu, out_split=out_s)
+            e = rel(out, ref); worst["small"] = max(worst["small"], e)
+            assert e < 4e-6, ("small gemm", M, N, K, e)
+            assert rel(out_s.to_float(), ref) < 4e-6 and bool(torch.isfinite(out_s.data.view(torch.float16).float()).all())
+            n_small += 1
+        elif sub == 3:   # un-embed store
+            Hz, Wz, p1 = int(rng.integers(1, 6)), int(rng.integers(1, 9)), int(rng.choice([1, 2, 4]))
+            cout, d = int(rng.choice([1, 3, 16, 40])), int(rng.choice([32, 52, 144, 360]))
+            a = torch.randn(Hz * Wz, d, generator=g); w = torch.randn(p1 * 4 * cout, d, generator=g) * 0.05
+            lin = (a.double() @ w.double().t()).view(Hz, Wz, p1, 4, cout)
+            ref = lin.permute(4, 0, 2, 1, 3).reshape(cout, Hz * p1, Wz * 4)
+            wps = w.view(p1, 4, cout, d).permute(2, 0, 1, 3).reshape(p1 * 4 * cout, d).contiguous()
+            img = torch.full((cout, Hz * p1, Wz * 4), 9.0, device=dev)
+            ops.small_gemm_nt_split(ops.split_f16(a.to(dev)), ops.split_f16(wps.to(dev), "auto"), out=img,
+                                    unembed=(Hz, Wz, p1, 4))
+            e = rel(img, ref); worst["small"] = max(worst["small"], e)
+            assert e < 4e-6, ("unembed", Hz, Wz, p1, cout, d, e)
+            n_small += 1
+        elif sub == 4:   # key-split exact-fp32 attention
+            n = int(rng.choice([1, 5, 16, 17, 63, 64, 65, 100, 648, 700])); heads = int(rng.integers(1, 6))
+            hd = int(rng.choice([64, 72])); C = heads * hd
+            qkv = torch.randn(n, 3 * C, generator=g) * float(rng.choice([0.5, 1.5, 4.0]))
+            q, k, v = qkv.double().view(n, 3, heads, hd).permute(1, 2, 0, 3)
+            ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).permute(1, 0, 2).reshape(n, C)
+            so = ops.SplitMat.empty(n, C, dev, zero=True)
+            out = ops.hyper_attention(qkv.to(dev), heads, out=torch.empty(n, C, device=dev), out_split=so)
+            e = rel(out, ref); worst["hatt"] = max(worst["hatt"], e)
+            assert e < 4e-6 and rel(so.to_float(), ref) < 4e-6, ("hyper attention", n, heads, hd, e)
+            n_hatt += 1
+        else:            # conv / deconv of the CNN zoo (k, stride, padding k//2, output_padding stride-1)
+            cin, cout = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+            k, st = [(5, 2), (3, 1), (5, 1), (3, 2)][int(rng.integers(0, 4))]
+            H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            x = torch.randn(cin, H, W, generator=g); b = torch.randn(cout, generator=g)
+            if rng.random() < 0.5:
+                w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+                ref = torch.nn.functional.conv2d(x.double()[None], w.double(), b.double(), st, k // 2)[0]
+                out = ops.conv2d(x.to(dev), ops.split_f16(w.reshape(cout, -1).to(dev), "auto"), b.to(dev), k, st)
+            else:
+                w = torch.randn(cin, cout, k, k, generator=g) * 0.1
+                ref = torch.nn.functional.conv_transpose2d(x.double()[None], w.double(), b.double(), st, k // 2, st - 1)[0]
+                out = ops.conv_transpose2d(x.to(dev), ops.split_f16(w.reshape(cin, -1).t().contiguous().to(dev), "auto"),
+                                           b.to(dev), cout, k, st)
+            assert tuple(out.shape) == tuple(ref.shape), (out.shape, ref.shape)
+            e = rel(out, ref); worst["conv"] = max(worst["conv"], e)
+            assert e < 4e-6, ("conv", cin, cout, k, st, H, W, e)
+            n_conv += 1
+        continue
     if kind < 6:
         M = int(rng.choice([1, 7, 33, 64, 100, 192, 255, 256, 257, 500, 648, 1000, 2048, 3000, 10368]))
         N = int(rng.choice([1, 5, 8, 31, 32, 36, 64, 77, 250, 256, 360, 512, 1024, 1080, 3072, 4096]))
@@ -41,8 +109,10 @@ while time.time() < t_end:
         else:
             pad = int(rng.choice([0, 4, 12]))
             buf = torch.full((M, N + pad), 7.0, device=dev)
+            sk = bool(rng.random() < 0.3)    # the persistent stream-K schedule where it is legal for the shape
             out = ops.gemm_nt_split(sa, sw, bias=None if bias is None else bias.to(dev), res=None if res is None else res.to(dev),
-                                    gelu=gelu, out=buf[:, :N], out_split=out_s)
+                                    gelu=gelu, out=buf[:, :N], out_split=out_s, sk_ws=sk_ws if sk else None,
+                                    sk=True if sk else None)
             if pad: assert bool((buf[:, N:] == 7.0).all()), ("wrote outside the view", M, N, K)
             if out_s is not None:
                 e2 = rel(out_s.to_float(), ref); assert e2 < 4e-6, ("split out", M, N, K, e2)
@@ -90,4 +160,6 @@ while time.time() < t_end:
         assert e < 4e-6, ("layernorm", rows, D, e)
         n_ln += 1
 torch.cuda.synchronize()
-print(f"fuzz ok: {n_gemm} gemm, {n_att} attention, {n_ln} layernorm cases; worst relative rmse {worst}")
+assert int(sk_ws[:4096].view(torch.int32).abs().sum()) == 0
+print(f"fuzz ok: {n_gemm} gemm, {n_att} attention, {n_ln} layernorm, {n_small} small-gemm / un-embed, {n_hatt} hyper-attention, "
+      f"{n_conv} conv / deconv cases; worst relative rmse {worst}")
