@@ -82,6 +82,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
 #ifndef ATT_LDS_PAD
 #define ATT_LDS_PAD 0
 #endif
+#ifndef ATT_PRIO_PV
+#define ATT_PRIO_PV 0
+#endif
 #ifndef ATT_VALU_PER_MFMA
 #define ATT_VALU_PER_MFMA 12
 #endif
@@ -142,6 +145,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+#ifdef ATT_PRIO_STATIC   /* experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): the later-dispatched waves */
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(ATT_PRIO_STATIC);
+#endif
   const int n_tiles = L / 32;
   uint4 sk0 = make_uint4(0u, 0u, 0u, 0u), sk1 = sk0, sv0 = sk0, sv1 = sk0;
   // K: 16 lanes cover one 256-byte row (coalesced).  V: 32 lanes cover 32 keys at the same
@@ -258,12 +264,26 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a_), "+v"(b_));              \
     fmaxf(a_, b_);                                                                        \
   })
+#if defined(ATT_PLAIN_SPLIT) || defined(ATT_NO_MAX3) || !defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_TILE_MAX(S)                                                                  \
   ({                                                                                      \
     float m_ = fmaxf(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])), fmaxf(fmaxf(S[4], S[5]), fmaxf(S[6], S[7]))); \
     float n_ = fmaxf(fmaxf(fmaxf(S[8], S[9]), fmaxf(S[10], S[11])), fmaxf(fmaxf(S[12], S[13]), fmaxf(S[14], S[15]))); \
     CRA5_XHALF_MAX(fmaxf(m_, n_)) * cexp; /* cexp > 0: max commutes with the scale */      \
   })
+#else
+// 16 scores -> their max in 8 VALU (v_max3_f32 tree) instead of 15 v_max_f32.  Plain C in the shape hipcc folds
+// into v_max3_f32: as inline asm the instruction would read MFMA results without the wait states the hazard
+// recogniser inserts for instructions it can see (NaNs).
+#define CRA5_MAX3(A, B, C) fmaxf(fmaxf((A), (B)), (C))
+#define CRA5_TILE_MAX(S)                                                                  \
+  ({                                                                                      \
+    const float a_ = CRA5_MAX3(S[0], S[1], S[2]), b_ = CRA5_MAX3(S[3], S[4], S[5]), c_ = CRA5_MAX3(S[6], S[7], S[8]); \
+    const float d_ = CRA5_MAX3(S[9], S[10], S[11]), e_ = CRA5_MAX3(S[12], S[13], S[14]);     \
+    const float f_ = CRA5_MAX3(a_, b_, c_), g_ = CRA5_MAX3(d_, e_, S[15]);                   \
+    CRA5_XHALF_MAX(fmaxf(f_, g_)) * cexp; /* cexp > 0: max commutes with the scale */      \
+  })
+#endif
 
   // prologue: K(0), V(0), K(1) resident; K(2), V(1) in flight; S(0) done
   CRA5_K_LOAD(0);
@@ -305,6 +325,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     }
     // ---- tile j+1's 12 score MFMAs, interleaved with tile j's softmax VALU work
     // (past the last tile the scores of a stale K buffer are computed and discarded.)
+#ifdef ATT_PRIO_SOFTMAX   /* experiment: this wave's softmax VALU (and its S MFMAs) outrank the other waves' streams */
+    __builtin_amdgcn_s_setprio(ATT_PRIO_SOFTMAX);
+#endif
     f32x16 s_next;
 #ifdef ATT_SKIP_S
     s_next = s_cur;
@@ -313,6 +336,37 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
 #endif
     float psum = 0.f;
     half8 ph[2], pl[2];
+#if !defined(ATT_PLAIN_SPLIT) && !defined(ATT_SKIP_SOFTMAX) && defined(__HIP_DEVICE_COMPILE__)
+    // p -> (hi, lo) with lo = p - f32(hi) as ONE v_fma_mix_f32 that reads the f16 half in place (no
+    // v_cvt_f32_f16 + v_sub per element): 4 VALU per two scores instead of 7.  MFMA and VALU of the waves of a
+    // SIMD do not overlap on this chip: every VALU removed here is wall time.  Only the
+    // fma_mix is inline asm (hipcc folds fma(x, -1, p) back into a subtraction); the conversions on both sides
+    // stay compiler-generated, so the registers the PV MFMAs read are written by instructions whose MFMA
+    // wait states the hazard recogniser knows.
+    {
+      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s_cur[r], cexp, -m_new));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s_cur[r + 1], cexp, -m_new));
+        psum += p0;
+        psum += p1;
+        const half2v h2 = {(_Float16)p0, (_Float16)p1};
+        const unsigned hh = __builtin_bit_cast(unsigned, h2);
+        float d0, d1;
+        // (s_nop: p0 / p1 come out of v_exp_f32, and gfx950 needs a wait state between a transcendental and a
+        // VALU that reads its result - inserted by hipcc for its own instructions, not for inline asm: without
+        // it one of four window shapes produced garbage)
+        asm("s_nop 0\n\tv_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(d0), "=&v"(d1) : "v"(hh), "v"(p0), "v"(p1));
+        ph[r >> 3][r & 7] = h2[0];
+        ph[r >> 3][(r & 7) + 1] = h2[1];
+        pl[r >> 3][r & 7] = (_Float16)d0;
+        pl[r >> 3][(r & 7) + 1] = (_Float16)d1;
+      }
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
 #if defined(ATT_SKIP_SOFTMAX)
@@ -329,7 +383,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
       pl[r >> 3][r & 7] = lo;
 #endif
     }
+#endif
     l_run += psum;
+#ifdef ATT_PRIO_SOFTMAX
+    __builtin_amdgcn_s_setprio(ATT_PRIO_PV);
+#endif
     // ---- O^T += V^T . P^T, with the staging traffic and tile j+1's max in its shadow
 #ifdef ATT_SKIP_PV
     o[0][0] += (float)ph[0][0] + (float)pl[1][7] + (float)ph[1][3] + (float)pl[0][5];
