@@ -304,11 +304,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
 
   // Waves past the end of the window (q_tok < 0 for all lanes) run the same instruction stream
   // on the pad row and store nothing: one code path, no divergent barriers.
-#ifdef ATT_NOLOOP   /* timing experiment: prologue + epilogue only */
-  for (int j = 0; j < 0; ++j) {
-#else
-  for (int j = 0; j < n_tiles; ++j) {
-#endif
+  // One key tile; the loop below is unrolled by two with the score registers swapping roles, so that tile j+1's
+  // scores never have to be copied into tile j's registers (8 v_mov_b64 per tile).
+  auto key_tile = [&](const int j, const f32x16 &s_cur, f32x16 &s_next) __attribute__((always_inline)) {
     const int kb = (j + 1) & 1, vb = j & 1;
     // tile j's running max is known before its softmax starts (mloc was reduced in the shadow of
     // the previous tile's PV MFMAs), so the rare O rescale sits at the top and everything below
@@ -328,7 +326,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
 #ifdef ATT_PRIO_SOFTMAX   /* experiment: this wave's softmax VALU (and its S MFMAs) outrank the other waves' streams */
     __builtin_amdgcn_s_setprio(ATT_PRIO_SOFTMAX);
 #endif
-    f32x16 s_next;
 #ifdef ATT_SKIP_S
     s_next = s_cur;
 #else
@@ -415,8 +412,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
       o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], ph[t], o[1], 0, 0, 0);
     }
 #endif
-    s_cur = s_next;
-    mloc = CRA5_TILE_MAX(s_cur);
+    mloc = CRA5_TILE_MAX(s_next);
 #ifdef ATT_SGB
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 K-fragment ds_reads first
 #pragma unroll
@@ -437,7 +433,19 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
 #ifndef ATT_SKIP_BARRIER
     __syncthreads();
 #endif
+  };
+  f32x16 s_alt;
+#ifdef ATT_NOLOOP   /* timing experiment: prologue + epilogue only */
+  const int n_loop = 0;
+#else
+  const int n_loop = n_tiles;
+#endif
+  int jt = 0;
+  for (; jt + 1 < n_loop; jt += 2) {
+    key_tile(jt, s_cur, s_alt);
+    key_tile(jt + 1, s_alt, s_cur);
   }
+  if (jt < n_loop) key_tile(jt, s_cur, s_alt);
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (q_tok >= 0) {
