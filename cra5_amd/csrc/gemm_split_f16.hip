@@ -116,7 +116,17 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
 #endif
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int tid = threadIdx.x;
+  // the wave index as a SCALAR for the 256 x 256 tiles: everything derived from it - the LDS-DMA destinations
+  // above all - stays in SGPRs (m0 = s_add instead of v_add_u32 + v_readfirstlane_b32 + s_mov per 1-KB DMA
+  // instruction; 42 -> 28 instructions per k-step of staging).  Measured, interleaved A/B: qkv 184 -> 175 us,
+  // fc1 279 -> 270, un-embed 1776 -> 1670; the 192 x 256 instantiation got 2-3 % SLOWER with it (fc2 233 -> 241)
+  // and keeps the vector form.  (A uniform byte cursor + 32-bit lane offsets did NOT make hipcc pick the
+  // saddr + voffset encoding for __builtin_amdgcn_global_load_lds: it rebuilt a 64-bit address per instruction.)
+#ifdef GEMM_WAVE_VGPR   /* A/B: the round-1 form everywhere */
   const int lane = tid & 63, wave = tid >> 6;
+#else
+  const int lane = tid & 63, wave = (TM == 4 && NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+#endif
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int nk_all = Kp / BK;
