@@ -107,7 +107,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   const int win = wh_id / heads;
   const int wr = win / g.nwc, wc = win - wr * g.nwc;
 
+  #ifdef ATT_WAVE_SCALAR
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
   const int l31 = lane & 31, h = lane >> 5;
   const int hoff = head * HD;
   // halves offset of this head's q / k / v slice inside a split row (64 d = 2 chunks = 128 halves)

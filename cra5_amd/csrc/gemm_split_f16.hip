@@ -124,8 +124,13 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   // saddr + voffset encoding for __builtin_amdgcn_global_load_lds: it rebuilt a 64-bit address per instruction.)
 #ifdef GEMM_WAVE_VGPR   /* A/B: the round-1 form everywhere */
   const int lane = tid & 63, wave = tid >> 6;
+  const int wave_dma = wave;
+#elif defined(GEMM_WAVE_DMA_ONLY)   /* A/B: scalar only where the LDS-DMA destination is formed */
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_dma = __builtin_amdgcn_readfirstlane(tid >> 6);
 #else
   const int lane = tid & 63, wave = (TM == 4 && NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  const int wave_dma = wave;
 #endif
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   {                                                                                            \
     _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                          \
       if (GROUPS % NWAVE == 0 || wave + q * NWAVE < GROUPS)                                    \
-        CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave + q * NWAVE) * 512);                     \
+        CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave_dma + q * NWAVE) * 512);                 \
       src[q] += 64;  /* next k-step: 128 B further along the row */                            \
     }                                                                                          \
   }
@@ -292,6 +297,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   if (nk > 1) CRA5_STAGE_LOAD(1);
   CRA5_TRACE(1);
 
+#ifdef GEMM_UNROLL2
+#pragma unroll 2
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const unsigned short *st = lds + cur * STAGE;
