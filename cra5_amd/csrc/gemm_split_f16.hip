@@ -67,6 +67,28 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return x * phi;
 }
 
+// two values at a time on the packed fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32): the epilogue has no MFMAs beside it
+// and is VALU-bound (the guide's "packed fp32 beside MFMAs is an anti-lever" does not apply here); same
+// arithmetic per element as gelu_erf, same operation order -> bit-identical results.
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v gelu_erf2(float2v x) {
+  const float2v t = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
+  const float2v d = __builtin_elementwise_fma(float2v{0.4f, 0.4f}, t, float2v{1.0f, 1.0f});
+  const float2v k = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  float2v p = {0.03080804832279682f, 0.03080804832279682f};
+  p = __builtin_elementwise_fma(p, k, float2v{-0.3524225652217865f, -0.3524225652217865f});
+  p = __builtin_elementwise_fma(p, k, float2v{1.0205539464950562f, 1.0205539464950562f});
+  p = __builtin_elementwise_fma(p, k, float2v{-0.7088391780853271f, -0.7088391780853271f});
+  p = __builtin_elementwise_fma(p, k, float2v{0.6733116507530212f, 0.6733116507530212f});
+  p = __builtin_elementwise_fma(p, k, float2v{0.0958886444568634f, 0.0958886444568634f});
+  p = __builtin_elementwise_fma(p, k, float2v{0.2406993806362152f, 0.2406993806362152f});
+  const float2v a = -(t * t) * 1.4426950408889634f;
+  const float2v e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const float2v half_erfc = 0.5f * p * k * e;
+  const float2v phi = {(x[0] >= 0.f) ? 1.0f - half_erfc[0] : half_erfc[0], (x[1] >= 0.f) ? 1.0f - half_erfc[1] : half_erfc[1]};
+  return x * phi;
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   const int q = nb / 8, r = nb % 8;
   const int xcd = bid % 8, within = bid / 8;

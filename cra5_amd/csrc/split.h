@@ -45,6 +45,30 @@ __device__ __forceinline__ void cra5_split(float v, _Float16 &hi, _Float16 &lo) 
   lo = (_Float16)(vc - (float)hi);
 }
 
+// Two values -> packed (hi, hi) and (lo, lo) f16 pairs.  lo = x - f32(hi) is ONE v_fma_mix_f32 reading the f16 half
+// in place (no v_cvt_f32_f16 + v_sub); the conversions on both sides stay compiler-generated (packed
+// v_cvt_pk_f16_f32).  `s_nop 0`: a and b may come straight out of a transcendental (v_exp_f32 / v_rcp_f32 in the GELU
+// epilogue), and gfx950 wants a wait state between a transcendental and a VALU that reads its result - hipcc inserts
+// it for its own instructions, not for inline asm (found the hard way in attention_split_f16.hip).
+__device__ __forceinline__ void cra5_split_pair(float a, float b, unsigned &hi2, unsigned &lo2) {
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  cra5_range_probe(a);
+  cra5_range_probe(b);
+  const float ac = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), bc = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
+  const half2v h2 = {(_Float16)ac, (_Float16)bc};
+  hi2 = __builtin_bit_cast(unsigned, h2);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CRA5_PLAIN_SPLIT)
+  float d0, d1;
+  asm("s_nop 0\n\tv_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(d0), "=&v"(d1) : "v"(hi2), "v"(ac), "v"(bc));
+#else
+  const float d0 = ac - (float)h2[0], d1 = bc - (float)h2[1];
+#endif
+  const half2v l2 = {(_Float16)d0, (_Float16)d1};
+  lo2 = __builtin_bit_cast(unsigned, l2);
+}
+
 __device__ __forceinline__ void cra5_store_split(unsigned short *row, int n, float v) {
   _Float16 hi, lo;
   cra5_split(v, hi, lo);
@@ -55,14 +79,10 @@ __device__ __forceinline__ void cra5_store_split(unsigned short *row, int n, flo
 
 // four consecutive columns n..n+3 (n % 4 == 0): two 8-byte stores
 __device__ __forceinline__ void cra5_store_split4(unsigned short *row, int n, float a, float b, float c, float d) {
-  _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-  cra5_split(a, h0, l0);
-  cra5_split(b, h1, l1);
-  cra5_split(c, h2, l2);
-  cra5_split(d, h3, l3);
-  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-  half4 hv = {h0, h1, h2, h3}, lv = {l0, l1, l2, l3};
+  unsigned h01, l01, h23, l23;
+  cra5_split_pair(a, b, h01, l01);
+  cra5_split_pair(c, d, h23, l23);
   unsigned short *p = row + (n >> 5) * 64 + (n & 31);
-  *reinterpret_cast<half4 *>(p) = hv;
-  *reinterpret_cast<half4 *>(p + 32) = lv;
+  *reinterpret_cast<uint2 *>(p) = make_uint2(h01, h23);
+  *reinterpret_cast<uint2 *>(p + 32) = make_uint2(l01, l23);
 }
