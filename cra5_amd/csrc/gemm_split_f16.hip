@@ -319,35 +319,53 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   if (nk > 1) CRA5_STAGE_LOAD(1);
   CRA5_TRACE(1);
 
-#ifdef GEMM_UNROLL2
-#pragma unroll 2
-#endif
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const unsigned short *st = lds + cur * STAGE;
-    CRA5_FRAG_READ(f1ah, f1al, f1bh, f1bl, st, 1);
-    CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
+  // One k-step.  -DGEMM_UNROLL2 unrolls the loop by two with the stage index a literal (fragment addresses of both
+  // stages loop-invariant, no 10 v_add_u32 per step; `#pragma unroll 2` is ignored on this loop: barrier + branches):
+  // measured 1.5-3 % SLOWER on every shape (11 address registers spill in the 256 x 256 instantiation, twice the
+  // loop body in the instruction cache) - off.
+#define CRA5_K_STEP(KT, CUR)                                                                     \
+  {                                                                                              \
+    CRA5_FRAG_READ(f1ah, f1al, f1bh, f1bl, lds + (CUR)*STAGE, 1);                                \
+    CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);                                                     \
+    CRA5_K_BARRIER;   /* tile kt+1 visible to everyone; everyone is done reading tile kt's stage */ \
+    if ((KT) + 1 < nk) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds + ((CUR) ^ 1) * STAGE, 0);     \
+    /* (dealing the DMA instructions out between the MFMAs instead of issuing them here in a burst  \
+       measured the same: 76-78 us per tile either way) */                                       \
+    CRA5_K_STAGE(KT, CUR);                                                                       \
+    CRA5_MFMA_GROUP(f1ah, f1al, f1bh, f1bl);                                                     \
+    if (LONGK && (((KT) & 15) == 15)) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
+          _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                       \
+            master[i][j][r] += acc[i][j][r];                                                     \
+            acc[i][j][r] = 0.f;                                                                  \
+          }                                                                                      \
+    }                                                                                            \
+  }
 #ifndef GEMM_SKIP_BARRIER   /* GEMM_SKIP_* : timing experiments of tools/gemm_trace.py (wrong results) */
-    __syncthreads();   // tile kt+1 visible to everyone; everyone is done reading tile kt's stage
+#define CRA5_K_BARRIER __syncthreads()
+#else
+#define CRA5_K_BARRIER
 #endif
-    if (kt + 1 < nk) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds + (cur ^ 1) * STAGE, 0);
 #ifndef GEMM_SKIP_STAGE
-    // (dealing the DMA instructions out between the MFMAs instead of issuing them here in a burst
-    // measured the same: 76-78 us per tile either way)
-    if (kt + 2 < nk) CRA5_STAGE_LOAD(cur);
+#define CRA5_K_STAGE(KT, CUR) if ((KT) + 2 < nk) CRA5_STAGE_LOAD(CUR)
+#else
+#define CRA5_K_STAGE(KT, CUR)
 #endif
-    CRA5_MFMA_GROUP(f1ah, f1al, f1bh, f1bl);
-    if (LONGK && ((kt & 15) == 15)) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            master[i][j][r] += acc[i][j][r];
-            acc[i][j][r] = 0.f;
-          }
+  {
+    int kt = 0;
+#ifdef GEMM_UNROLL2
+    for (; kt + 1 < nk; kt += 2) {
+      CRA5_K_STEP(kt, 0);
+      CRA5_K_STEP(kt + 1, 1);
     }
+    if (kt < nk) CRA5_K_STEP(kt, 0);
+#else
+    for (; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      CRA5_K_STEP(kt, cur);
+    }
+#endif
   }
   __syncthreads();   // the epilogue reuses the stages as scratch
 
