@@ -144,6 +144,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   // fc1 279 -> 270, un-embed 1776 -> 1670; the 192 x 256 instantiation got 2-3 % SLOWER with it (fc2 233 -> 241)
   // and keeps the vector form.  (A uniform byte cursor + 32-bit lane offsets did NOT make hipcc pick the
   // saddr + voffset encoding for __builtin_amdgcn_global_load_lds: it rebuilt a 64-bit address per instruction.)
+#ifndef GEMM_SCALAR_ALL
+#define GEMM_SCALAR_ALL 0
+#endif
 #ifdef GEMM_WAVE_VGPR   /* A/B: the round-1 form everywhere */
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_dma = wave;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_dma = __builtin_amdgcn_readfirstlane(tid >> 6);
 #else
-  const int lane = tid & 63, wave = (TM == 4 && NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  const int lane = tid & 63, wave = ((TM == 4 || GEMM_SCALAR_ALL) && NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int wave_dma = wave;
 #endif
   const int wm = wave / WN, wn = wave % WN;
@@ -331,8 +334,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
     if ((KT) + 1 < nk) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds + ((CUR) ^ 1) * STAGE, 0);     \
     /* (dealing the DMA instructions out between the MFMAs instead of issuing them here in a burst  \
        measured the same: 76-78 us per tile either way) */                                       \
-    CRA5_K_STAGE(KT, CUR);                                                                       \
+    CRA5_K_STAGE_EARLY(KT, CUR);                                                                 \
     CRA5_MFMA_GROUP(f1ah, f1al, f1bh, f1bl);                                                     \
+    CRA5_K_STAGE_LATE(KT, CUR);                                                                  \
     if (LONGK && (((KT) & 15) == 15)) {                                                          \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
@@ -351,6 +355,13 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
 #define CRA5_K_STAGE(KT, CUR) if ((KT) + 2 < nk) CRA5_STAGE_LOAD(CUR)
 #else
 #define CRA5_K_STAGE(KT, CUR)
+#endif
+#ifdef GEMM_STAGE_LATE   /* experiment: issue the LDS-DMA of tile kt+2 after the step's second MFMA group: 4-9 % slower */
+#define CRA5_K_STAGE_EARLY(KT, CUR)
+#define CRA5_K_STAGE_LATE(KT, CUR) CRA5_K_STAGE(KT, CUR)
+#else
+#define CRA5_K_STAGE_EARLY(KT, CUR) CRA5_K_STAGE(KT, CUR)
+#define CRA5_K_STAGE_LATE(KT, CUR)
 #endif
   {
     int kt = 0;
