@@ -279,7 +279,9 @@ def layernorm(x, gamma, beta, eps=1e-6, out=None, out_split=None, want_f32=True)
                                    out_split.Kp if out_split is not None else 0, rows, D, float(eps), _stream()),
           "cra5_layernorm_f32")
     if ev is not None:   # bytes: the row read once + every output written once
-        TIMER.stop("layernorm", ev, 4.0 * rows * D * (1 + (out is not None) + (out_split is not None)))
+        # (the 648-row hyper-prior LayerNorms are launch-latency-bound: kept out of the HBM-bound figure)
+        TIMER.stop("layernorm" if rows >= 4096 else "layernorm_small", ev,
+                   4.0 * rows * D * (1 + (out is not None) + (out_split is not None)))
     return out if out is not None else out_split
 
 
