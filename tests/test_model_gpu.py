@@ -531,3 +531,49 @@ def test_api_batch_methods_pinned_pipeline(thin, dev, tmp_path):
         assert np.array_equal(d.cpu().numpy().reshape(8, 721, 1440), out[i]) and rec[i] is not None
     dn = api.decode_from_bin(stamps[1], return_format="normalized")["x_hat"]
     assert np.array_equal(dn.cpu().numpy().reshape(8, 721, 1440), rec_n[1])
+
+
+def test_hyper_prior_engine_is_pinned_across_engine_settings(thin, thin_side, dev):
+    """the decoder re-derives every CDF index from h_s(z_hat); the engine behind h_a / h_s must not
+    depend on CRA5_GEMM / CRA5_ATTN / the precision mode, or a stream written under one setting desynchronises
+    when read under another.  Encode with the default engines, decode with the exact-f32 engines and with the
+    reduced-precision mode selected: the latent that comes back is bit-identical every time."""
+    x, y, s = thin_side
+    out = thin.compress_from_latent(y)
+    keep = (thin.gemm_mode, thin.attn_mode, thin.precision)
+    try:
+        for gm, am, pr in (("f32", "f32", "fp32"), ("split", "f32", "fp32"), ("split", "split", "f16")):
+            thin.gemm_mode, thin.attn_mode, thin.precision = gm, am, pr
+            y_hat = thin.decompress(out["strings"], out["z_shape"], return_format='latent')
+            assert torch.equal(y_hat[0].reshape(-1), s["y_hat"].reshape(-1)), (gm, am, pr)
+            s2 = thin._latent_side_frame(y[0])
+            assert torch.equal(s2["idx"], s["idx"]) and torch.equal(s2["y_sym"], s["y_sym"]), (gm, am, pr)
+    finally:
+        thin.gemm_mode, thin.attn_mode, thin.precision = keep
+
+
+def test_full268_pipeline_distinct_frames_equal_serial(big, dev):
+    """BASELINE configs[3] in miniature on one GPU: distinct frames x_f ~ N(0,1) (seed 1000 + f) through the frame
+    pipeline, several in flight on their own streams - every frame's two byte streams equal its serial compress()."""
+    from cra5_amd.pipeline import FramePipeline
+    g = torch.Generator(device=dev)
+    frames = []
+    for f in range(3):
+        g.manual_seed(1000 + f)
+        frames.append(torch.randn((1, 268, 721, 1440), generator=g, device=dev))
+    serial = [big.compress(f)["strings"] for f in frames]
+    assert len({s[0][0] for s in serial}) == 3                     # the frames really differ
+    keep = (big.gpu_exclusive, big.gpu_slots)
+    pipe = FramePipeline(big, workers=3)
+    try:
+        big.gpu_exclusive, big.gpu_slots = False, 2
+        outs = pipe.compress([frames[i % 3] for i in range(6)])
+        for i, o in enumerate(outs):
+            assert o["strings"] == serial[i % 3]
+        rec = pipe.decompress(outs[:3])
+        for i in range(3):
+            ref = big.decompress(serial[i], outs[i]["z_shape"])["x_hat"]
+            assert torch.equal(rec[i]["x_hat"], ref)
+    finally:
+        big.gpu_exclusive, big.gpu_slots = keep
+        pipe.close()
