@@ -122,8 +122,12 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   if (!GLOBAL) {
     const long long pad_delta = reinterpret_cast<const char *>(pad_row) - reinterpret_cast<const char *>(qkv);
     for (int t = tid; t < L; t += NT) {
+#ifdef ATT_TAB_TRIVIAL   /* timing experiment: no div / mod in the table build (wrong rows) */
+      tab[t] = (long long)t * ldq * 2 + (pad_delta & 0);
+#else
       const int tok = token_of(g, wr, wc, t);
       tab[t] = (tok >= 0) ? (long long)tok * ldq * 2 : pad_delta;
+#endif
     }
   }
   const bool wave_active = __any(q_tok >= 0);
