@@ -33,7 +33,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file flags.  gemm_split_f16.hip: the epilogue's row-block loop must unroll FULLY in every instantiation (a
 # dynamically indexed accumulator array lives in scratch); the 128 x 128-per-wave one exceeds clang's default
 # 16 K-instruction budget for `#pragma unroll`.
-EXTRA = {"gemm_split_f16.hip": ["-mllvm", "-pragma-unroll-threshold=262144"]}
+# -Wno-inline-asm: the hand-written LDS-DMA names m0 as a clobber (it is the DMA's LDS base by definition).
+EXTRA = {"gemm_split_f16.hip": ["-mllvm", "-pragma-unroll-threshold=262144", "-Wno-inline-asm"]}
 
 FLAVOURS = {
     "release": dict(host=["-O3"], dev=["-O3"], link=[]),

@@ -147,6 +147,14 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
 #ifndef GEMM_SCALAR_ALL
 #define GEMM_SCALAR_ALL 0
 #endif
+// Hand-written LDS-DMA (saddr + voffset encoding, no address VALU in the k-loop): on by default for the 256 x 256
+// and the 192 x 256 instantiations; -DGEMM_NO_ASM_DMA builds the __builtin_amdgcn_global_load_lds form everywhere.
+#if !defined(GEMM_NO_ASM_DMA) && !defined(GEMM_ASM_DMA)
+#define GEMM_ASM_DMA
+#endif
+#ifndef GEMM_ASM_DMA_192
+#define GEMM_ASM_DMA_192 1
+#endif
 #ifdef GEMM_WAVE_VGPR   /* A/B: the round-1 form everywhere */
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_dma = wave;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_dma = __builtin_amdgcn_readfirstlane(tid >> 6);
 #else
-  const int lane = tid & 63, wave = ((TM == 4 || GEMM_SCALAR_ALL) && NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  const int lane = tid & 63, wave = ((TM == 4 || GEMM_SCALAR_ALL || GEMM_ASM_DMA_192) && NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int wave_dma = wave;
 #endif
   const int wm = wave / WN, wn = wave % WN;
@@ -216,6 +224,22 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   constexpr int IPW = (GROUPS + NWAVE - 1) / NWAVE;              // LDS-DMA instructions per wave per k-step
   static_assert(NPROD == 1 || GROUPS % NWAVE == 0, "groups must divide evenly over the waves");
   const unsigned short *src[IPW];
+#ifdef GEMM_ASM_DMA
+  // Hand-written LDS-DMA with the saddr + voffset encoding: a uniform 64-bit cursor per operand (advanced by an
+  // s_add per k-step) + a fixed 32-bit byte offset per lane and instruction - no address VALU in the k-loop (the
+  // builtin form spends a v_lshl_add_u64 per instruction per k-step, and hipcc does not pick this encoding for it).
+  // Measured, interleaved A/B: qkv 182 -> 176 us, un-embed 1762 -> 1736, proj 75.6 -> 72.1, fc2 251 -> 245,
+  // patch-embed chunk 459 -> 438.  The loads are invisible to hipcc's s_waitcnt insertion: the prologue and
+  // CRA5_K_BARRIER wait with an explicit s_waitcnt vmcnt(0) (exactly the DMA of the tile the barrier publishes is
+  // outstanding there).  The per-lane offsets are relative to the tile's first row (< 256 rows x the row pitch: the
+  // launcher refuses pitches of 2^21 k-columns (2^22 halves) and more, far above anything the path has).
+  constexpr bool ASM_DMA = ((TM == 4 || (GEMM_ASM_DMA_192 && TM == 3)) && NPROD == 3 && WM == 2 && WN == 4 && !LONGK);
+  static_assert(!ASM_DMA || BM % (WM * WN * 8) == 0, "A / W staging instructions must not straddle");
+  unsigned soff[IPW];
+  unsigned long long curA = 0, curW = 0;
+#else
+  constexpr bool ASM_DMA = false;
+#endif
   // NPROD == 3: one instruction = 8 rows x 128 B: a row's [32 hi | 32 lo] chunk is one cache line, requested
   // once (16 rows x 64 B of one plane per instruction asked for every line twice: -3..6 % on the 192x256
   // tiles).  LDS rows are 128 B = 8 pieces [hi 0-3 | lo 4-7]; piece p of row r lives at physical piece
@@ -235,14 +259,46 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
         src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + lpiece * 8 + (size_t)ka * 64;
       else
         src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + lpiece * 8 + (size_t)ka * 64;
+#ifdef GEMM_ASM_DMA
+      if (ASM_DMA)
+        soff[q] = (unsigned)((((size_t)(isA ? (size_t)(min(m0 + row_, M - 1) - m0) * lda : (size_t)(min(n0 + row_, N - 1) - n0) * ldw)) + lpiece * 8) * 2);
+#endif
     }
   }
+#ifdef GEMM_ASM_DMA
+  if (ASM_DMA) {
+    curA = reinterpret_cast<unsigned long long>(A + (size_t)m0 * lda) + (unsigned long long)ka * 128;
+    curW = reinterpret_cast<unsigned long long>(W + (size_t)n0 * ldw) + (unsigned long long)ka * 128;
+  }
+#endif
   // (the builtin only exists in the device pass; the host pass just needs the launch stub)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_GLDS16(SRC, DST) __builtin_amdgcn_global_load_lds(SRC, DST, 16, 0, 0)
 #else
 #define CRA5_GLDS16(SRC, DST) (void)(SRC)
 #endif
+#if defined(GEMM_ASM_DMA) && defined(__HIP_DEVICE_COMPILE__)
+#define CRA5_STAGE_LOAD(BUF)                                                                   \
+  {                                                                                            \
+    if (ASM_DMA) {                                                                             \
+      /* BM = BN = 256, 8 waves: instructions q < 4 stage A rows, q >= 4 stage W rows */       \
+      const unsigned ldsb_ = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned short *)(lds + (BUF)*STAGE)); \
+      _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                        \
+        const unsigned dst_ = ldsb_ + (wave_dma + q * NWAVE) * 1024;                           \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"          \
+                     :: "s"(dst_), "v"(soff[q]), "s"((q * NWAVE * 8 < BM) ? curA : curW) : "memory", "m0"); \
+      }                                                                                        \
+      curA += 128;                                                                             \
+      curW += 128;                                                                             \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                        \
+        if (GROUPS % NWAVE == 0 || wave + q * NWAVE < GROUPS)                                  \
+          CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave_dma + q * NWAVE) * 512);               \
+        src[q] += 64;                                                                          \
+      }                                                                                        \
+    }                                                                                          \
+  }
+#else
 #define CRA5_STAGE_LOAD(BUF)                                                                   \
   {                                                                                            \
     _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                          \
@@ -251,6 +307,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
       src[q] += 64;  /* next k-step: 128 B further along the row */                            \
     }                                                                                          \
   }
+#endif
 
   f32x16 acc[TM][TN];
   f32x16 master[LONGK ? TM : 1][LONGK ? TN : 1];
@@ -317,6 +374,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   const int nk = kb - ka;
   half8 f0ah[TM], f0al[TM], f0bh[TN], f0bl[TN], f1ah[TM], f1al[TM], f1bh[TN], f1bl[TN];
   CRA5_STAGE_LOAD(0);
+#ifdef GEMM_ASM_DMA
+  if (ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   __syncthreads();   // (hipcc drains vmcnt before the barrier: tile 0 has landed for everyone)
   CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds, 0);
   if (nk > 1) CRA5_STAGE_LOAD(1);
@@ -346,7 +406,9 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
           }                                                                                      \
     }                                                                                            \
   }
-#ifndef GEMM_SKIP_BARRIER   /* GEMM_SKIP_* : timing experiments of tools/gemm_trace.py (wrong results) */
+#if defined(GEMM_ASM_DMA)
+#define CRA5_K_BARRIER { if (ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#elif !defined(GEMM_SKIP_BARRIER)   /* GEMM_SKIP_* : timing experiments of tools/gemm_trace.py (wrong results) */
 #define CRA5_K_BARRIER __syncthreads()
 #else
 #define CRA5_K_BARRIER
@@ -557,6 +619,7 @@ extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t 
                                   int M, int N, int Kp, float wscale_inv, int flags, void *stream) {
   if (!A || !W || (!C && !C_split) || M <= 0 || N <= 0 || Kp <= 0 || (Kp % BK)) return CRA5_ERR_ARG;
   if (lda_kp < Kp || ldw_kp < Kp || (lda_kp % 32) || (ldw_kp % 32)) return CRA5_ERR_ARG;
+  if (lda_kp >= (1 << 21) || ldw_kp >= (1 << 21)) return CRA5_ERR_ARG;   // 32-bit tile-relative DMA offsets (2 halves per k)
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return CRA5_ERR_ARG;
   if ((flags & CRA5_EPI_BIAS) && !bias) return CRA5_ERR_ARG;
   if ((flags & CRA5_EPI_RES) && !res) return CRA5_ERR_ARG;
@@ -628,6 +691,7 @@ extern "C" int cra5_gemm_nt_split_sk(const uint16_t *A, int lda_kp, const uint16
     return cra5_gemm_nt_split(A, lda_kp, W, ldw_kp, C, ldc, C_split, ldc_split_kp, bias, res, ldr, M, N, Kp, wscale_inv,
                               flags, stream);
   if (!A || !W || (!C && !C_split) || lda_kp < Kp || ldw_kp < Kp || (lda_kp % 32) || (ldw_kp % 32)) return CRA5_ERR_ARG;
+  if (lda_kp >= (1 << 21) || ldw_kp >= (1 << 21)) return CRA5_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return CRA5_ERR_ARG;
   if ((flags & CRA5_EPI_BIAS) && !bias) return CRA5_ERR_ARG;
   if ((flags & CRA5_EPI_RES) && !res) return CRA5_ERR_ARG;

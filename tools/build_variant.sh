@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 name=$1; src=$2; defs=$3
 python -m cra5_amd.build >/dev/null
 mkdir -p build_variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=262144 $defs -c cra5_amd/csrc/$src -o build_variants/${name}_${src%.hip}.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=262144 -Wno-inline-asm $defs -c cra5_amd/csrc/$src -o build_variants/${name}_${src%.hip}.o
 objs=""
 for f in host_entropy gemm_f32 gemm_split_f16 attention_f32 attention_split_f16 elementwise hyper; do
   if [ "$f.hip" == "$src" ]; then objs="$objs build_variants/${name}_${f}.o"; else objs="$objs cra5_amd/csrc/$f.o"; fi
