@@ -207,7 +207,23 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
       my_slot = 2 * pid;
     }
   }
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  // Tile order: the 32 work-groups an XCD runs at a time own 32 CONSECUTIVE tile numbers (xcd_remap), so tiles are
+  // numbered in bands of GEMM_GROUP_M tile rows, column-major inside a band: 32 consecutive tiles = 4 A panels x 8 W
+  // panels through that XCD's L2 per round (12 panel reads) instead of 2 x 16 (18) in row-major order.
+#ifndef GEMM_GROUP_M
+#define GEMM_GROUP_M 4
+#endif
+  int tm, tn;
+  if (GEMM_GROUP_M > 1) {
+    const int tiles_m = (M + BM - 1) / BM;
+    const int band = tile / (GEMM_GROUP_M * tiles_n), r = tile - band * (GEMM_GROUP_M * tiles_n);
+    const int rows = min(tiles_m - band * GEMM_GROUP_M, GEMM_GROUP_M);
+    tn = r / rows;
+    tm = band * GEMM_GROUP_M + (r - tn * rows);
+  } else {
+    tm = tile / tiles_n;
+    tn = tile % tiles_n;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   // Staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 1 KB straight into LDS -
