@@ -115,7 +115,7 @@ struct SkArgs {
 };
 
 template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3, bool SK = false>
-__global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_split_kernel(
+__global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM == 3)) ? 2 : 1)) void gemm_nt_split_kernel(
     const unsigned short *__restrict__ A, long lda, const unsigned short *__restrict__ W, long ldw, float *C,
     int ldc, unsigned short *Cs, long ldcs, const float *__restrict__ bias, const float *res, int ldr, int M,
     int N, int Kp, float wscale_inv, int flags, int tiles_n, SkArgs sk) {
@@ -130,7 +130,12 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
 
   // two stages of [A rows][W rows], 128 B per row = [32 hi | 32 lo] of one k-step, XOR-swizzled in
   // 16-byte pieces (see the staging comment below); 2 x (BM + BN) x 128 B, no padding.
-  __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE];
+#if defined(GEMM_PF)
+  constexpr int PF_SINK = (TM >= 3 && NPROD == 3 && WM == 2 && WN == 4 && !LONGK) ? WM * WN * 128 : 0;   // halves
+#else
+  constexpr int PF_SINK = 0;
+#endif
+  __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE + PF_SINK];
 
   CRA5_TRACE(0);
 #ifdef CRA5_GEMM_TRACE
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   // CRA5_K_BARRIER wait with an explicit s_waitcnt vmcnt(0) (exactly the DMA of the tile the barrier publishes is
   // outstanding there).  The per-lane offsets are relative to the tile's first row (< 256 rows x the row pitch: the
   // launcher refuses pitches of 2^21 k-columns (2^22 halves) and more, far above anything the path has).
-  constexpr bool ASM_DMA = ((TM == 4 || (GEMM_ASM_DMA_192 && TM == 3)) && NPROD == 3 && WM == 2 && WN == 4 && !LONGK);
+  constexpr bool ASM_DMA = ((TM == 4 || (GEMM_ASM_DMA_192 && TM == 3)) && NPROD == 3 && WM == 2 && (WN == 4 || (WN == 2 && TM == 3)) && !LONGK);
   static_assert(!ASM_DMA || BM % (WM * WN * 8) == 0, "A / W staging instructions must not straddle");
   unsigned soff[IPW];
   unsigned long long curA = 0, curW = 0;
@@ -287,11 +292,55 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
     curW = reinterpret_cast<unsigned long long>(W + (size_t)n0 * ldw) + (unsigned long long)ka * 128;
   }
 #endif
+  // L2 prefetch (GEMM_PF): the work-groups that share an operand panel run in lock-step, so the LDS-DMA of a k-slice
+  // is the FIRST touch of its lines for a whole XCD - every DMA pays the fabric latency (Infinity Cache / HBM), not the
+  // L2 hit latency, and two 64-KB stages only cover one k-step of it (elimination run: without the DMA the kernel is
+  // 15-25 % faster).  One dword load per wave and k-step - lane l touches the line of row (l & 7) of this wave's DMA
+  // instruction (l >> 3), PF_DIST k-steps beyond the tile being staged - pulls those lines into L2 ahead of time.
+  // Nobody waits for it: it is issued right after a stage's DMA instructions and the barrier waits with vmcnt(1).
+#if defined(GEMM_PF) && defined(GEMM_ASM_DMA)
+  constexpr bool PF = ASM_DMA;
+#else
+  constexpr bool PF = false;
+#endif
+#ifndef GEMM_PF_DIST
+#define GEMM_PF_DIST 2
+#endif
+  const unsigned short *pf_ptr = A;
+  int pf_tile = 0;
+  const unsigned pf_sink_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned short *)(lds + STAGES * STAGE)) + wave_dma * 256;
+  if (PF) {
+    const int q = min(lane >> 3, IPW - 1), grow = (wave + q * NWAVE) * 8;
+    const bool isA = grow < BM;
+    const int row_ = (isA ? grow : grow - BM) + (lane & 7);
+    pf_tile = min(1 + GEMM_PF_DIST, kb - ka - 1);
+    pf_ptr = (isA ? A + (size_t)min(m0 + row_, M - 1) * lda : W + (size_t)min(n0 + row_, N - 1) * ldw) +
+             (size_t)(ka + pf_tile) * 64;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRA5_PF_ISSUE                                                                          \
+  if (PF) {                                                                                    \
+    /* the sink is a 256-byte LDS slot per wave behind the stages: a VGPR destination would be clobbered when the   \
+       load returns, long after hipcc has given the register to something else */                                   \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"                \
+                 :: "s"(pf_sink_lds), "v"(pf_ptr) : "memory", "m0");                           \
+    const bool more_ = pf_tile + 1 < kb - ka;                                                  \
+    pf_tile += more_ ? 1 : 0;                                                                  \
+    pf_ptr += more_ ? 64 : 0;                                                                  \
+  }
+#else
+#define CRA5_PF_ISSUE
+#endif
   // (the builtin only exists in the device pass; the host pass just needs the launch stub)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_GLDS16(SRC, DST) __builtin_amdgcn_global_load_lds(SRC, DST, 16, 0, 0)
 #else
 #define CRA5_GLDS16(SRC, DST) (void)(SRC)
+#endif
+#ifdef GEMM_DMA_SAMEK   /* timing experiment, wrong results: every k-step stages the same (cache-resident) k-slice */
+#define CRA5_DMA_KSTRIDE 0
+#else
+#define CRA5_DMA_KSTRIDE 128
 #endif
 #if defined(GEMM_ASM_DMA) && defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_STAGE_LOAD(BUF)                                                                   \
@@ -304,8 +353,8 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"          \
                      :: "s"(dst_), "v"(soff[q]), "s"((q * NWAVE * 8 < BM) ? curA : curW) : "memory", "m0"); \
       }                                                                                        \
-      curA += 128;                                                                             \
-      curW += 128;                                                                             \
+      curA += CRA5_DMA_KSTRIDE;                                                                \
+      curW += CRA5_DMA_KSTRIDE;                                                                \
     } else {                                                                                   \
       _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                        \
         if (GROUPS % NWAVE == 0 || wave + q * NWAVE < GROUPS)                                  \
@@ -389,13 +438,83 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
   // pipe idled through barrier skew + the first ds_reads of the new stage, 20 of 78 us per tile.
   const int nk = kb - ka;
   half8 f0ah[TM], f0al[TM], f0bh[TN], f0bl[TN], f1ah[TM], f1al[TM], f1bh[TN], f1bl[TN];
+#if defined(GEMM_PINGPONG) && defined(GEMM_ASM_DMA)
+  constexpr bool PP = ASM_DMA;
+#else
+  constexpr bool PP = false;
+#endif
+  // Ping-pong main loop (PP): the two waves of a SIMD (wave w and w + 4: wm = 0 | 1) run the same four phases per
+  // k-step - read the fragments of a 16-wide half, MFMA it, read the other half, MFMA it - ONE PHASE APART, a raw
+  // s_barrier at every phase boundary: while one wave of the SIMD feeds the matrix pipe (24 back-to-back MFMAs,
+  // s_setprio 1) the other does its ds_reads / LDS-DMA issue and waits at the barrier.  (MFMA and the LDS / VALU
+  // work of the other wave do not overlap on a SIMD on this chip - DESIGN.md section 9 - so interleaving them inside
+  // each wave, as the 2-phase loop below does, leaves the matrix pipe idle whenever both waves read.)
+  // Intervals t = 4 kt + {0..3} for wm = 0 and one later for wm = 1.  Tile kt + 1 goes into the stage tile kt - 1
+  // vacated (last read: wm = 1, interval 4 kt - 1) and is issued in interval 4 kt by BOTH groups (wm = 0 in its read
+  // phase, wm = 1 at the top of its MFMA phase), each wave drains its own DMA (vmcnt(0)) before the barrier that
+  // ends interval 4 kt + 3, the first read of the tile is in interval 4 kt + 4.
+#define CRA5_PP_BARRIER                        \
+  {                                            \
+    asm volatile("" ::: "memory");             \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0);         \
+    asm volatile("" ::: "memory");             \
+  }
+#ifdef GEMM_PP_SKIPDMA   /* timing experiment, wrong results */
+#define CRA5_PP_DMA_ON false
+#else
+#define CRA5_PP_DMA_ON true
+#endif
+#ifdef GEMM_PP_NOPRIO
+#define CRA5_PP_PRIO(P)
+#else
+#define CRA5_PP_PRIO(P) __builtin_amdgcn_s_setprio(P)
+#endif
+#ifdef GEMM_PP_SKIPREAD   /* timing experiment, wrong results: fragments read once */
+#define CRA5_PP_READ(ST, KK) if (kt == 0) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, ST, KK)
+#else
+#define CRA5_PP_READ(ST, KK) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, ST, KK)
+#endif
+  if (PP) {
+    CRA5_STAGE_LOAD(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CRA5_TRACE(1);
+    if (wm == 1) {
+      if (nk > 1) { CRA5_STAGE_LOAD(1); CRA5_PF_ISSUE; }
+      CRA5_PP_BARRIER;
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned short *st = lds + (kt & 1) * STAGE;
+      if (wm == 0 && kt + 1 < nk && CRA5_PP_DMA_ON) { CRA5_STAGE_LOAD((kt + 1) & 1); CRA5_PF_ISSUE; }
+      CRA5_PP_READ(st, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CRA5_PP_BARRIER;
+      CRA5_PP_PRIO(1);
+      CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
+      CRA5_PP_PRIO(0);
+      CRA5_PP_BARRIER;
+      CRA5_PP_READ(st, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (wm == 1) { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      CRA5_PP_BARRIER;
+      if (wm == 1 && kt + 2 < nk && CRA5_PP_DMA_ON) { CRA5_STAGE_LOAD(kt & 1); CRA5_PF_ISSUE; }
+      CRA5_PP_PRIO(1);
+      CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
+      CRA5_PP_PRIO(0);
+      if (wm == 0) { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      CRA5_PP_BARRIER;
+    }
+    if (wm == 0) CRA5_PP_BARRIER;
+  } else {
   CRA5_STAGE_LOAD(0);
 #ifdef GEMM_ASM_DMA
   if (ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   __syncthreads();   // (hipcc drains vmcnt before the barrier: tile 0 has landed for everyone)
   CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds, 0);
-  if (nk > 1) CRA5_STAGE_LOAD(1);
+  if (nk > 1) { CRA5_STAGE_LOAD(1); CRA5_PF_ISSUE; }
   CRA5_TRACE(1);
 
   // One k-step.  -DGEMM_UNROLL2 unrolls the loop by two with the stage index a literal (fragment addresses of both
@@ -423,14 +542,14 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
     }                                                                                            \
   }
 #if defined(GEMM_ASM_DMA)
-#define CRA5_K_BARRIER { if (ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#define CRA5_K_BARRIER { if (ASM_DMA) { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
 #elif !defined(GEMM_SKIP_BARRIER)   /* GEMM_SKIP_* : timing experiments of tools/gemm_trace.py (wrong results) */
 #define CRA5_K_BARRIER __syncthreads()
 #else
 #define CRA5_K_BARRIER
 #endif
 #ifndef GEMM_SKIP_STAGE
-#define CRA5_K_STAGE(KT, CUR) if ((KT) + 2 < nk) CRA5_STAGE_LOAD(CUR)
+#define CRA5_K_STAGE(KT, CUR) if ((KT) + 2 < nk) { CRA5_STAGE_LOAD(CUR); CRA5_PF_ISSUE; }
 #else
 #define CRA5_K_STAGE(KT, CUR)
 #endif
@@ -456,6 +575,7 @@ __global__ __launch_bounds__(WM *WN * 64, (STAGES == 1 ? 2 : 1)) void gemm_nt_sp
     }
 #endif
   }
+  }   // !PP
   __syncthreads();   // the epilogue reuses the stages as scratch
 
   CRA5_TRACE(2);
@@ -624,6 +744,11 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
   // LDS fragment traffic per MFMA - compiles spill-free but measured 4-5 % SLOWER with hipcc's schedule: qkv 197 vs
   // 190 us, un-embed 1922 vs 1832; a single wave per SIMD needs a hand-placed MFMA / ds_read / LDS-DMA interleave)
   if (tile == 64) CRA5_GO(2, 2, 1, 1, false);
+#ifdef GEMM_TILE_193   /* experiment: 192 x 128 tiles on 4 waves, 80 KB of LDS = two independent work-groups per CU (one's epilogue
+                         beside the other's main loop): qkv 170 -> 198 us, un-embed 1678 -> 1765, fc1 258 -> 254 - the main loop
+                         pays more for the 1.67 x LDS-DMA traffic per MFMA than the overlap returns */
+  if (tile == 193) CRA5_GO(2, 2, 3, 2, false);
+#endif
   if (tile == 192) CRA5_GO(2, 4, 3, 2, false);   // 192 x 256, 8 waves (2 x 4), 3 x 2 sub-tiles per wave
   if (tile == 256) CRA5_GO(2, 4, 4, 2, false);   // 256 x 256, 8 waves (2 x 4), 4 x 2 sub-tiles per wave
   CRA5_GO(2, 2, 2, 2, false);
