@@ -438,21 +438,25 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // pipe idled through barrier skew + the first ds_reads of the new stage, 20 of 78 us per tile.
   const int nk = kb - ka;
   half8 f0ah[TM], f0al[TM], f0bh[TN], f0bl[TN], f1ah[TM], f1al[TM], f1bh[TN], f1bl[TN];
-#if defined(GEMM_PINGPONG) && defined(GEMM_ASM_DMA)
+#if !defined(GEMM_NO_PINGPONG) && defined(GEMM_ASM_DMA)
   constexpr bool PP = ASM_DMA;
 #else
   constexpr bool PP = false;
 #endif
-  // Ping-pong main loop (PP): the two waves of a SIMD (wave w and w + 4: wm = 0 | 1) run the same four phases per
-  // k-step - read the fragments of a 16-wide half, MFMA it, read the other half, MFMA it - ONE PHASE APART, a raw
-  // s_barrier at every phase boundary: while one wave of the SIMD feeds the matrix pipe (24 back-to-back MFMAs,
-  // s_setprio 1) the other does its ds_reads / LDS-DMA issue and waits at the barrier.  (MFMA and the LDS / VALU
-  // work of the other wave do not overlap on a SIMD on this chip - DESIGN.md section 9 - so interleaving them inside
-  // each wave, as the 2-phase loop below does, leaves the matrix pipe idle whenever both waves read.)
-  // Intervals t = 4 kt + {0..3} for wm = 0 and one later for wm = 1.  Tile kt + 1 goes into the stage tile kt - 1
-  // vacated (last read: wm = 1, interval 4 kt - 1) and is issued in interval 4 kt by BOTH groups (wm = 0 in its read
-  // phase, wm = 1 at the top of its MFMA phase), each wave drains its own DMA (vmcnt(0)) before the barrier that
-  // ends interval 4 kt + 3, the first read of the tile is in interval 4 kt + 4.
+  // Ping-pong main loop (PP; the 256 x 256 and 192 x 256 instantiations): the two waves of a SIMD (wave w and w + 4:
+  // wm = 0 | 1) run the same four phases per k-step - read the fragments of a 16-wide k-half, MFMA it, read the
+  // other half, MFMA it - ONE PHASE APART, a raw s_barrier at every phase boundary: while one wave of the SIMD feeds
+  // the matrix pipe (TM x TN x 3 back-to-back MFMAs) the other does its ds_reads and its LDS-DMA issue and waits at
+  // the barrier.  MFMA and the LDS / VMEM work of the partner wave do not overlap on a SIMD on this chip (DESIGN.md
+  // section 9), and a wave that issues its DMA burst next to its own MFMAs stalls them (the asymmetric variant -
+  // wm = 1 issuing at the top of an MFMA phase - was 2-5 % slower than the 2-phase loop below; this one is 3-10 %
+  // faster: qkv 169 -> 164 us, fc1 263 -> 250, fc2 237 -> 216, patch-embed chunk 436 -> 391, un-embed 1690 -> 1623).
+  // One fragment register set instead of two.
+  // Intervals t = 4 kt + {0, 1, 2, 3} (wm = 0) and one later (wm = 1).  The DMA of tile kt + 1 goes into the stage
+  // tile kt - 1 vacated (its last read: wm = 1, interval 4 kt - 1, retired by the lgkmcnt(0) before that barrier) and
+  // is issued by every wave in its first read phase of tile kt (intervals 4 kt and 4 kt + 1); each wave drains its
+  // own DMA (vmcnt(0)) before the barrier that ends interval 4 kt + 3 - wm = 0 behind its second MFMA phase, wm = 1 in
+  // its second read phase - and the first read of tile kt + 1 is in interval 4 kt + 4.
 #define CRA5_PP_BARRIER                        \
   {                                            \
     asm volatile("" ::: "memory");             \
@@ -461,49 +465,38 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     __builtin_amdgcn_sched_barrier(0);         \
     asm volatile("" ::: "memory");             \
   }
-#ifdef GEMM_PP_SKIPDMA   /* timing experiment, wrong results */
+#ifdef GEMM_PP_SKIPDMA   /* timing experiments of tools/ab_bench.sh (wrong results) */
 #define CRA5_PP_DMA_ON false
 #else
 #define CRA5_PP_DMA_ON true
 #endif
-#ifdef GEMM_PP_NOPRIO
-#define CRA5_PP_PRIO(P)
-#else
-#define CRA5_PP_PRIO(P) __builtin_amdgcn_s_setprio(P)
-#endif
-#ifdef GEMM_PP_SKIPREAD   /* timing experiment, wrong results: fragments read once */
+#ifdef GEMM_PP_SKIPREAD
 #define CRA5_PP_READ(ST, KK) if (kt == 0) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, ST, KK)
 #else
 #define CRA5_PP_READ(ST, KK) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, ST, KK)
 #endif
+#define CRA5_PP_DRAIN { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   if (PP) {
     CRA5_STAGE_LOAD(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CRA5_TRACE(1);
-    if (wm == 1) {
-      if (nk > 1) { CRA5_STAGE_LOAD(1); CRA5_PF_ISSUE; }
-      CRA5_PP_BARRIER;
-    }
+    if (wm == 1) CRA5_PP_BARRIER;   // the second group runs one interval behind
     for (int kt = 0; kt < nk; ++kt) {
       const unsigned short *st = lds + (kt & 1) * STAGE;
-      if (wm == 0 && kt + 1 < nk && CRA5_PP_DMA_ON) { CRA5_STAGE_LOAD((kt + 1) & 1); CRA5_PF_ISSUE; }
       CRA5_PP_READ(st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk && CRA5_PP_DMA_ON) { CRA5_STAGE_LOAD((kt + 1) & 1); CRA5_PF_ISSUE; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       CRA5_PP_BARRIER;
-      CRA5_PP_PRIO(1);
       CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
-      CRA5_PP_PRIO(0);
       CRA5_PP_BARRIER;
       CRA5_PP_READ(st, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (wm == 1) { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      if (wm == 1) CRA5_PP_DRAIN;
       CRA5_PP_BARRIER;
-      if (wm == 1 && kt + 2 < nk && CRA5_PP_DMA_ON) { CRA5_STAGE_LOAD(kt & 1); CRA5_PF_ISSUE; }
-      CRA5_PP_PRIO(1);
       CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
-      CRA5_PP_PRIO(0);
-      if (wm == 0) { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      if (wm == 0) CRA5_PP_DRAIN;
       CRA5_PP_BARRIER;
     }
     if (wm == 0) CRA5_PP_BARRIER;
