@@ -288,11 +288,16 @@ class cra5_api:
         """host array (numpy / CPU tensor, physical units) -> this thread's device frame buffer, through
         this thread's pinned staging buffer, on the current stream."""
         net = self.net
-        src = arr if isinstance(arr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
-        if src.is_cuda:
-            return src.to(torch.float32)
-        pin = net._pinned("api_x_in", tuple(src.shape), torch.float32)
-        pin.copy_(src)                                  # host memcpy, GIL released
+        if isinstance(arr, torch.Tensor):
+            if arr.is_cuda:
+                return arr.to(torch.float32)
+            arr = arr.numpy()
+        pin = net._pinned("api_x_in", tuple(arr.shape), torch.float32)
+        # host memcpy (+ dtype conversion) by numpy on THIS thread, GIL released: torch's copy_ fans one 1.11 GB copy out
+        # over every core of the box (128 threads: 11 GB/s, one thread: 24 GB/s - tools/api_host_probe.sh) and the
+        # twelve frame threads then fight over them; twelve single-threaded copies run side by side
+        np.copyto(pin.numpy(), arr, casting="same_kind")
+        src = pin
         xdev = net._buf("api_x_dev", tuple(src.shape))
         xdev.copy_(pin, non_blocking=True)              # async H2D on this frame's stream
         return xdev
