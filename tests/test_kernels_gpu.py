@@ -46,7 +46,10 @@ def test_gemm_nt(dev, M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (10368, 1024, 1024), (2048, 4096, 1024), (1000, 360, 360),
-                                   (333, 77, 52), (10368, 1024, 4096), (2048, 1024, 29480), (648, 8192, 360)])
+                                   (333, 77, 52), (10368, 1024, 4096), (2048, 1024, 29480), (648, 8192, 360),
+                                   # the big-tile ping-pong main loop at 1, 2, 3 and 5 k-steps (prologue / drain edges),
+                                   # ragged last tile rows / columns, both tile shapes (N >= 2048: 256 x 256, else 192 x 256)
+                                   (2100, 2304, 32), (2100, 2304, 64), (4099, 1030, 96), (3000, 2050, 160)])
 def test_gemm_split_f16_is_fp32_accurate(dev, M, N, K):
     """The 3xf16-split MFMA GEMM against float64, side by side with the exact-f32 MFMA kernel:
     it must be at least as accurate (shorter fp32 accumulation chain), never worse than 1.5x."""
@@ -98,6 +101,25 @@ def test_split_producers(dev):
     sc = ops.SplitMat.empty(72 * 144, 330, dev, zero=True)
     ops.im2col(img, 11, 10, 10, 10, out_split=sc)
     assert float((sc.to_float() - c).abs().max()) <= 2 ** -21 * float(c.abs().max()) + 2 ** -24
+
+
+@pytest.mark.parametrize("M,N,K", [(10368, 3072, 1024), (10368, 1024, 4096)])
+def test_gemm_big_tiles_race_screen(dev, M, N, K):
+    """The ping-pong main loop orders its LDS-DMA and fragment reads by counted waits + barriers only: an early read
+    would pass whenever the DMA happens to land first.  Fifty launches under memory load (a concurrent copy stream)
+    must be bit-identical."""
+    g = torch.Generator().manual_seed(5)
+    a = ops.split_f16(torch.randn(M, K, generator=g).to(dev))
+    w = ops.split_f16((torch.randn(N, K, generator=g) * 0.03).to(dev), "auto")
+    first = ops.gemm_nt_split(a, w).clone()
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device=dev)
+    for it in range(50):
+        with torch.cuda.stream(side):
+            junk.mul_(1.0001)                     # HBM traffic beside the GEMM
+        out = ops.gemm_nt_split(a, w)
+        assert torch.equal(out, first), it
+    torch.cuda.synchronize()
 
 
 def test_gemm_asymmetric_layout(dev):
