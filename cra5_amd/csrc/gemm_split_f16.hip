@@ -637,9 +637,36 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
 #undef EPI_MODE
     }
   } else {
+    // interior tiles of the four epilogue shapes the model uses take the straight-line body; everything else (edge
+    // tiles, unaligned outputs, both outputs at once, long-K master accumulators) the generic one
+#ifndef GEMM_NO_FAST_EPILOGUE
+    const bool interior = !LONGK && !SK && m0 + BM <= M && n0 + BN <= N;
+    const bool c_only = C && !Cs && vecC && !do_gelu;
+    const bool s_only = Cs && !C && !has_res && ((ldcs & 3) == 0) && ((reinterpret_cast<size_t>(Cs) & 7) == 0);
+    const bool bias_ok = has_bias || true;   // bv[] is zero without a bias
+    if (TM <= 3 && interior && bias_ok && c_only && has_res && vecR) {   // (TM = 4: the two residual buffers do not fit 256 registers)
+#define EPI_KIND 0
+#include "gemm_split_epilogue_fast.inc"
+#undef EPI_KIND
+    } else if (interior && s_only && !do_gelu) {
+#define EPI_KIND 1
+#include "gemm_split_epilogue_fast.inc"
+#undef EPI_KIND
+    } else if (interior && s_only && do_gelu) {
+#define EPI_KIND 2
+#include "gemm_split_epilogue_fast.inc"
+#undef EPI_KIND
+    } else if (interior && c_only && !has_res) {
+#define EPI_KIND 3
+#include "gemm_split_epilogue_fast.inc"
+#undef EPI_KIND
+    } else
+#endif
+    {
 #define EPI_MODE 0
 #include "gemm_split_epilogue.inc"
 #undef EPI_MODE
+    }
   }
   if (SK) __syncthreads();   // the next item's LDS-DMA overwrites the epilogue scratch
   }  // item loop
