@@ -66,10 +66,11 @@ __device__ __forceinline__ int token_of(const WinGeom &g, int wr, int wc, int t)
 constexpr int HD = 64;
 constexpr int KS = 72;   // K LDS row stride (halves): 144 B
 constexpr int VS = 96;   // V LDS row stride (halves): 192 B - see the ds_read_b64_tr_b16 note in the kernel
-constexpr int MAX_WIN_TOKENS = 1536;   // windowed (not whole-grid) launches: L <= this (12 KB offset table)
+constexpr int MAX_WIN_TOKENS = 1152;   // windowed (not whole-grid) launches: L <= this (9 KB offset table: three 4-wave
+                                        // work-groups of 52.7 KB each fit a CU's 160 KB)
 
 template <int NW, bool HI, bool GLOBAL>
-__global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_split_kernel(
+__global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void window_attention_split_kernel(
     const unsigned short *__restrict__ qkv, long ldq /* halves per row = 2*Kp */,
     const unsigned short *__restrict__ pad_row, float *__restrict__ out, unsigned short *__restrict__ out_s,
     int Kp_out, int C, int heads, WinGeom g, int q_tiles, float scale) {
@@ -132,6 +133,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     }
   }
   const bool wave_active = __any(q_tok >= 0);
+#ifdef ATT_NO_IDLE_SKIP
+  constexpr bool IDLE_SKIP = false;
+#else
+  constexpr bool IDLE_SKIP = !GLOBAL;
+#endif
   if (!__syncthreads_or(wave_active ? 1 : 0)) return;
 
   // ---- Q fragments: B operand of S^T = K.Q^T; step s covers d = 16s + 8h + (0..7) ---------
@@ -317,6 +323,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
   // scores never have to be copied into tile j's registers (8 v_mov_b64 per tile).
   auto key_tile = [&](const int j, const f32x16 &s_cur, f32x16 &s_next) __attribute__((always_inline)) {
     const int kb = (j + 1) & 1, vb = j & 1;
+    // (a wave whose 32 queries all lie past the end of the window - half of the fifth 128-query work-group of a
+    // 576-token window - only stages and synchronises: its MFMAs would be taken from the other waves of its SIMD)
+    if (!IDLE_SKIP || wave_active) {
     // tile j's running max is known before its softmax starts (mloc was reduced in the shadow of
     // the previous tile's PV MFMAs), so the rare O rescale sits at the top and everything below
     // is ONE basic block the scheduler can interleave.
@@ -424,6 +433,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : 2)) void window_attention_s
     }
 #endif
     mloc = CRA5_TILE_MAX(s_next);
+    }
 #ifdef ATT_SGB
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 K-fragment ds_reads first
 #pragma unroll
@@ -520,7 +530,15 @@ extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp
     if (hi_only) CRA5_ATT_GO(ATT_NW_GLOBAL, true, true);
     CRA5_ATT_GO(ATT_NW_GLOBAL, false, true);
   }
-  if (L % 192 == 0 && L <= 1152) {
+  // Windows: 4-wave work-groups (128 queries), three per CU.  The 6-wave form (192 queries: 3 exact blocks per 576-token
+  // window, K / V staged three times instead of five) looks better on paper and ran with ONE work-group per CU: its
+  // waves land on the SIMDs 2-2-1-1, a second work-group would put four 156-register waves on one SIMD (3 fit), so
+  // 864 work-groups took 3.4 rounds instead of 1.7.  Four waves are one per SIMD: three work-groups always fit.
+  // (-DATT_NW_WINDOW=6 selects the 6-wave form.)
+#ifndef ATT_NW_WINDOW
+#define ATT_NW_WINDOW 4
+#endif
+  if (ATT_NW_WINDOW == 6 && L % 192 == 0 && L <= 1152) {
     if (hi_only) CRA5_ATT_GO(6, true, false);
     CRA5_ATT_GO(6, false, false);
   }

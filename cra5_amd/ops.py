@@ -329,7 +329,7 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
     return out if out is not None else out_split
 
 
-MAX_WIN_TOKENS = 1536   # csrc/attention_split_f16.hip: windowed launches keep a per-block row-offset table
+MAX_WIN_TOKENS = 1152   # csrc/attention_split_f16.hip: windowed launches keep a per-block row-offset table
 
 
 def split_attention_ok(C, heads, wh, ww, H=None, W=None):
