@@ -186,7 +186,7 @@ int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out
  * cra5_gemm_nt_split), reading the split-f16 qkv matrix [H*W][3C] the qkv projection wrote
  * (qkv_kp = 3C) and a split pad row, writing fp32 `out` and/or split-f16 `out_split`.
  * Requires head dim 64 and wh*ww % 32 == 0 (the 576-token windows and the 10 368-token global
- * attention); a window that is not the whole grid must have <= 1536 tokens (CRA5_ERR_ARG otherwise);
+ * attention); a window that is not the whole grid must have <= 1152 tokens (CRA5_ERR_ARG otherwise);
  * other shapes use cra5_window_attention_f32.  hi_only != 0: reduced-precision mode
  * (plain f16 q/k/v/p operands, 8 MFMAs per tile instead of 24; fp32 softmax statistics). */
 int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
