@@ -24,11 +24,16 @@
 // [A rows | W rows], 128 B per row per k-step, filled by LDS-DMA (global_load_lds_dwordx4,
 // one cache line per row, XOR swizzle of the 16-byte piece index applied on the source
 // side -> conflict-free ds_read_b128 without padding, 256x256 double-buffered = 128 KB);
-// ONE barrier per BK = 32 step placed between the step's two 16-wide halves, with the next
-// tile's first-half fragments prefetched across it, so the matrix pipe never waits on the
-// barrier; MFMAs issued plane-major (TM*TN independent accumulators between dependent
-// MFMAs); XCD-aware tile order; epilogue through wave-private LDS (row-contiguous float4
-// accesses) with fused bias / erf-GELU / residual and fp32 and/or split-f16 output.  Long
+// main loop of the two big tiles: a PING-PONG between the two waves of each SIMD - one reads the
+// fragments of a 16-wide k-half and issues its LDS-DMA while the other issues that half's
+// TM*TN*3 MFMAs, a raw s_barrier at every phase boundary (LDS / VMEM work overlaps another
+// wave's MFMAs on this chip, VALU does not); the small tiles keep the 2-phase loop (ONE
+// barrier per BK = 32 step placed between the step's two 16-wide halves, the next tile's
+// first-half fragments prefetched across it); MFMAs issued plane-major (TM*TN independent
+// accumulators between dependent MFMAs); XCD-aware tile order in bands of four tile rows;
+// epilogue through wave-private LDS (row-contiguous float4 accesses) with fused bias /
+// erf-GELU / residual and fp32 and/or split-f16 output - a straight-line body for interior
+// tiles (gemm_split_epilogue_fast.inc), the generic one for edges.  Long
 // reductions (K > 8192: the patch-embed conv, K = 29 480) are chained through the fp32
 // output in chunks of <= 8192 (two-level sum).
 #include <hip/hip_runtime.h>
