@@ -201,6 +201,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        # N ranks share the node's host cores: keep every rank's torch CPU pool (weight preparation, the few host-side
+        # tensor ops of a frame) to its share instead of N pools of one thread per core each
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
 
     net = vaeformer_pretrained(quality=args.quality, pretrained=False)
     synth.load_synthetic(net, seed=7)
