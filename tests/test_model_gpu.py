@@ -531,6 +531,14 @@ def test_api_batch_methods_pinned_pipeline(thin, dev, tmp_path):
         assert np.array_equal(d.cpu().numpy().reshape(8, 721, 1440), out[i]) and rec[i] is not None
     dn = api.decode_from_bin(stamps[1], return_format="normalized")["x_hat"]
     assert np.array_equal(dn.cpu().numpy().reshape(8, 721, 1440), rec_n[1])
+    # host staging takes what the reference's xarray path can hand over: float64 arrays, CPU tensors, non-contiguous
+    # views - same bytes as the float32 frame
+    f64 = frames[2].astype(np.float64)
+    strided = np.ascontiguousarray(frames[2].transpose(0, 2, 1)).transpose(0, 2, 1)
+    alt = api.encode_era5_batch(["2024-06-02T00:00:00", "2024-06-02T01:00:00", "2024-06-02T02:00:00"],
+                                data=[f64, torch.from_numpy(frames[2]), strided], save_root=str(tmp_path / "alt"), workers=2)
+    want = open(res[2]["save_path"], "rb").read()
+    assert all(open(r["save_path"], "rb").read() == want for r in alt)
 
 
 def test_hyper_prior_engine_is_pinned_across_engine_settings(thin, thin_side, dev):
