@@ -1,5 +1,5 @@
-"""CNN zoo codecs on the MI355X kernels: `bmshj2018-factorized`, `bmshj2018-hyperprior`, `mbt2018-mean`
-(FactorizedPrior / ScaleHyperprior / MeanScaleHyperprior of the reference,
+"""CNN zoo codecs on the MI355X kernels: `bmshj2018-factorized`, `bmshj2018-factorized-relu`, `bmshj2018-hyperprior`,
+`mbt2018-mean` (FactorizedPrior / FactorizedPriorReLU / ScaleHyperprior / MeanScaleHyperprior of the reference,
 cra5/models/compressai/models/google.py:64-508) - SURVEY.md section 8(f)-4.
 
 Same module tree (state-dict keys `g_a.0.weight`, `g_a.1.beta`, ..., `h_s.4.bias`, entropy-model
@@ -17,7 +17,7 @@ from . import ops
 from .entropy import EntropyBottleneck, GaussianConditional, get_scale_table
 from .layers import GDN
 
-__all__ = ["FactorizedPrior", "ScaleHyperprior", "MeanScaleHyperprior", "cnn_model", "CNN_CFGS"]
+__all__ = ["FactorizedPrior", "FactorizedPriorReLU", "ScaleHyperprior", "MeanScaleHyperprior", "cnn_model", "CNN_CFGS"]
 
 
 class _Conv(nn.Module):
@@ -168,6 +168,17 @@ class FactorizedPrior(_CnnBase):
         return {"x_hat": torch.stack(out)}
 
 
+class FactorizedPriorReLU(FactorizedPrior):
+    """google.py:166-199 (`bmshj2018-factorized-relu`): the GDN / IGDN stages replaced by ReLU."""
+
+    def __init__(self, N, M, rate_distortion_loss=None, in_channel=3, **kwargs):
+        super().__init__(N, M, in_channel=in_channel)
+        self.g_a = _seq(_Conv(in_channel, N), _Act("relu"), _Conv(N, N), _Act("relu"), _Conv(N, N), _Act("relu"), _Conv(N, M))
+        self.g_s = _seq(_Deconv(M, N), _Act("relu"), _Deconv(N, N), _Act("relu"), _Deconv(N, N), _Act("relu"),
+                        _Deconv(N, in_channel))
+        self.eval()
+
+
 class ScaleHyperprior(_CnnBase):
     """google.py:227-383 (`bmshj2018-hyperprior`): zero-mean Gaussian conditional, scales from h_s(z_hat)."""
 
@@ -278,10 +289,12 @@ class MeanScaleHyperprior(ScaleHyperprior):
 # (N, M) per quality, zoo/image.py:202-245
 CNN_CFGS = {
     "bmshj2018-factorized": {q: (128, 192) if q <= 5 else (192, 320) for q in range(1, 9)},
+    "bmshj2018-factorized-relu": {q: (128, 192) if q <= 5 else (192, 320) for q in range(1, 9)},
     "bmshj2018-hyperprior": {q: (128, 192) if q <= 5 else (192, 320) for q in range(1, 9)},
     "mbt2018-mean": {q: (128, 192) if q <= 4 else (192, 320) for q in range(1, 9)},
 }
-_ARCH = {"bmshj2018-factorized": FactorizedPrior, "bmshj2018-hyperprior": ScaleHyperprior,
+_ARCH = {"bmshj2018-factorized": FactorizedPrior, "bmshj2018-factorized-relu": FactorizedPriorReLU,
+         "bmshj2018-hyperprior": ScaleHyperprior,
          "mbt2018-mean": MeanScaleHyperprior}
 
 

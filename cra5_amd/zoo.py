@@ -16,11 +16,14 @@ from .vaeformer import VAEformer
 
 from . import cnn as _cnn
 
-__all__ = ["vaeformer_pretrained", "bmshj2018_factorized", "bmshj2018_hyperprior", "mbt2018_mean", "load_pretrained",
+__all__ = ["vaeformer_pretrained", "bmshj2018_factorized", "bmshj2018_factorized_relu", "bmshj2018_hyperprior", "mbt2018_mean",
+           "load_pretrained",
            "rename_key", "model_architectures", "cfgs"]
 
-# zoo/image.py:56-62 / :202-245 (the autoregressive `mbt2018` and the ReLU variant are not built)
+# zoo/image.py:56-62 / :202-245 (the autoregressive `mbt2018` and the cheng2020 models are not built; the reference
+# registers the ReLU variant's class under an underscore key its own `_load_model` never finds - it is reachable here)
 model_architectures = {"vaeformer-pretrained": VAEformer, "bmshj2018-factorized": _cnn.FactorizedPrior,
+                       "bmshj2018-factorized-relu": _cnn.FactorizedPriorReLU,
                        "bmshj2018-hyperprior": _cnn.ScaleHyperprior, "mbt2018-mean": _cnn.MeanScaleHyperprior}
 cfgs = dict({"vaeformer-pretrained": {268: (268,), 159: (159,)}}, **_cnn.CNN_CFGS)
 _CKPT_NAMES = {268: "cra5_268v_300k.pth"}  # zoo/image.py:69-75
@@ -95,5 +98,6 @@ def _cnn_entry(architecture):
 
 
 bmshj2018_factorized = _cnn_entry("bmshj2018-factorized")     # zoo/image.py:326-348
+bmshj2018_factorized_relu = _cnn_entry("bmshj2018-factorized-relu")   # zoo/image.py:351-373
 bmshj2018_hyperprior = _cnn_entry("bmshj2018-hyperprior")     # zoo/image.py:376-398
 mbt2018_mean = _cnn_entry("mbt2018-mean")                     # zoo/image.py:401-423

@@ -357,6 +357,40 @@ def stage_cnn():
     print("cnn done")
 
 
+def stage_cnn_relu():
+    """FactorizedPriorReLU (models/google.py:166-199) like stage_cnn -> cnn_relu.npz.  As shipped the class cannot be
+    constructed: its __init__ ends in `MODELS.build(rate_distortion_loss)` (a training criterion) and the module never
+    imports a `MODELS` (NameError); the codec path never touches the criterion, so the name is bound to a registry
+    whose build() returns None."""
+    import types
+    from cra5.models.compressai.models import google
+    N, M = 32, 48
+    google.MODELS = types.SimpleNamespace(build=lambda cfg: None)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(1, 3, 128, 192, generator=g)
+    o = {}
+    net = google.FactorizedPriorReLU(N, M, None).eval()
+    load_synth(net, seed=11)
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    y = net.g_a(x)
+    o["y"] = y.numpy()
+    fw = net(x)
+    o["xhat_fw"] = sub(fw["x_hat"], 5)
+    o["bits_y"] = np.array([float((-torch.log2(fw["likelihoods"]["y"])).sum())])
+    gy = torch.Generator().manual_seed(5)
+    y_hat = torch.round(3.0 * torch.randn(y.shape, generator=gy))
+    o["xhat_synth"] = sub(net.g_s(y_hat), 5)
+    out = net.compress(x)
+    o["xhat_rt"] = sub(net.decompress(out["strings"], out["shape"])["x_hat"], 5)
+    o["string0"] = np.frombuffer(out["strings"][0][0], dtype=np.uint8)
+    o["shape"] = np.array(list(out["shape"]))
+    np.savez_compressed(os.path.join(HERE, "cnn_relu.npz"), **o)
+    sk = json.load(open(os.path.join(HERE, "state_keys.json")))
+    sk["cnn"]["factorized_relu"] = keys
+    json.dump(sk, open(os.path.join(HERE, "state_keys.json"), "w"))
+    print("cnn_relu done")
+
+
 def stage_stats():
     """The reference's cra5_api.get_mean_std / channel_vname_mapping run on the reference's own
     config + JSON files (the methods only read self.cfg / self.level_mapping, so they are called
@@ -435,5 +469,5 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for s in a.stage:
         dict(small=stage_small, thin=stage_thin, full=stage_full, full159=stage_full159, stats=stage_stats,
-             cnn=stage_cnn,
+             cnn=stage_cnn, cnn_relu=stage_cnn_relu,
              thin64=lambda: stage_fp64("thin"), full64=lambda: stage_fp64("full"))[s]()

@@ -71,6 +71,35 @@ def test_cnn_zoo_vs_reference_golden(dev, golden_dir, name, cls):
         assert rel(sub(rec2, 5), g[f"{name}_xhat_rt"]) <= 1e-5
 
 
+@gpu
+def test_factorized_relu_vs_reference_golden(dev, golden_dir):
+    """`bmshj2018-factorized-relu` (google.py:166-199) against the reference class (cnn_relu.npz, make_golden.py
+    --stage cnn_relu)."""
+    g = np.load(f"{golden_dir}/cnn_relu.npz")
+    keys = json.load(open(f"{golden_dir}/state_keys.json"))["cnn"]["factorized_relu"]
+    net = cnn.FactorizedPriorReLU(N, M)
+    synth.load_synthetic(net, seed=11)
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == keys
+    net = net.to(dev)
+    x = torch.from_numpy(np.load(f"{golden_dir}/cnn_zoo.npz")["x"]).to(dev)
+    y = net.g_a(x[0])
+    assert rel(y, g["y"]) <= 1e-5
+    fw = net(x)
+    assert rel(sub(fw["x_hat"], 5), g["xhat_fw"]) <= 1e-3
+    bits = float((-torch.log2(fw["likelihoods"]["y"].double())).sum())
+    assert abs(bits - g["bits_y"][0]) <= 2e-3 * g["bits_y"][0]
+    gy = torch.Generator().manual_seed(5)
+    y_hat = torch.round(3.0 * torch.randn((1,) + tuple(y.shape), generator=gy))[0].to(dev)
+    assert rel(sub(net.g_s(y_hat), 5), g["xhat_synth"]) <= 1e-5
+    out = net.compress(x)
+    assert list(out["shape"]) == list(g["shape"])
+    same = out["strings"][0][0] == g["string0"].tobytes()
+    print("factorized-relu: stream identical to the reference python's:", same, len(out["strings"][0][0]), len(g["string0"]))
+    assert abs(len(out["strings"][0][0]) - len(g["string0"])) <= 8
+    rec = net.decompress(out["strings"], out["shape"])
+    assert rel(sub(rec["x_hat"], 5), g["xhat_rt"]) <= (1e-5 if same else 1e-3)
+
+
 def test_cnn_zoo_entry_errors():
     with pytest.raises(ValueError, match="architecture"):
         cnn.cnn_model("nope", 1)
@@ -87,3 +116,5 @@ def test_cnn_zoo_entry_errors():
         zoo.mbt2018_mean(0)
     with pytest.raises(RuntimeError, match="not yet available"):
         zoo.bmshj2018_factorized(1, pretrained=True)
+    r = zoo.bmshj2018_factorized_relu(7)
+    assert isinstance(r, cnn.FactorizedPriorReLU) and (r.N, r.M) == (192, 320)
