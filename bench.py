@@ -2,7 +2,10 @@
 """bench.py - ERA5 frames/s (721x1440x268) encode+decode on N MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...)
+N > 1: either launch it under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env), or just run the line above - without WORLD_SIZE in
+the env bench.py re-launches ITSELF under torch.distributed.run with N ranks (one per GPU, RCCL), rank 0 prints
+the one JSON line, the exit code is the job's.
 
 A "step" is one pass of the hot path over one synthetic frame on each rank:
     x (268x721x1440 fp32, resident in HBM) -> g_a -> y -> h_a/EB/h_s/GC -> rANS .bin
@@ -36,6 +39,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (no sparsity)
 FLOP_PER_FRAME = 11.57e12      # encode 6.132 + decode 5.415 + hyper-prior
+_T, _D = 10368, 1024            # tokens, width of the 268 model
+# algorithmic flops per frame served by the two big-tile GEMM instantiations: 25 blocks x (qkv + proj + fc1 + fc2)
+# + patch-embed + un-embed (K = N = 268*11*10) + post_quant_conv + quant_conv = 7.80 TFLOP
+GEMM_BIGTILE_FLOP_PER_FRAME = 2.0 * _T * (25 * (_D * 3 * _D + _D * _D + 2 * _D * 4 * _D) + 2 * _D * 29480
+                                          + 256 * _D + 2 * _D * 512)
 
 
 def host_cpu_info():
@@ -151,6 +159,84 @@ def cpu_baseline(quality, n_threads):
                        f"un-extrapolated figure (`--cpu-baseline full`, one whole frame) is committed under profiles/")}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
+    torch.distributed.run (one process per GPU; 127.0.0.1 rendezvous on a free port).  stdout / stderr are
+    inherited, so rank 0's JSON line is this process's output; returns the job's exit code."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    env["CRA5_SELF_LAUNCHED"] = "1"
+    # torch.distributed.run forces OMP_NUM_THREADS=1 when it is unset; every rank sizes its own pools from its
+    # NUMA share of the cores instead (main())
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // (2 * n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, stdin=subprocess.DEVNULL)
+
+
+def dry_dist(args):
+    """`--dry-dist`: everything of the N-rank job EXCEPT the GPU work, on gloo / CPU - launch, rendezvous,
+    frame sharding, barrier, max-over-ranks, the all-gather of per-frame stats, one JSON line from rank 0.
+    Stand-in streams (the stats only look at bytes).  Used by tests/test_dist_cpu.py."""
+    from cra5_amd import dist as D
+    rank, world, local = D.init_from_env("cpu")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    cpu = torch.device("cpu")
+    my = D.shard_frames(world * args.steps, rank, world)
+    D.barrier()
+    t0 = time.perf_counter()
+    rows = [D.frame_stats(f, [[bytes([f % 251]) * (100 + f)], [bytes([(7 * f) % 251]) * (10 + f)]]) for f in my]
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0 + 1e-3 * (rank + 1), cpu)
+    stats = D.gather_stats(rows, cpu)
+    assert stats[:, 0].tolist() == list(range(world * args.steps)), "gathered stats do not cover the frame set"
+    if rank == 0:
+        print(json.dumps({"metric": "dry-dist (no GPU work)", "dry": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "value": world * args.steps / elapsed, "unit": "frames/s",
+                          "frames_of_rank0": [my[0], my[-1] + 1] if len(my) else [],
+                          "stats_rows": int(stats.shape[0]), "stats_bytes": int(stats[:, 1:3].sum()),
+                          "self_launched": os.environ.get("CRA5_SELF_LAUNCHED") == "1",
+                          "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None}),
+              flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def rocprof_gemm_frac():
+    """roofline fraction of the two big-tile GEMM instantiations from the newest committed rocprofv3 kernel
+    summary (profiles/r*_bench_exclusive_kernel_stats.csv): algorithmic flops per frame of the launches each
+    instantiation serves / (calls x average duration).  None if the file is absent."""
+    import csv
+    import glob
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_exclusive_kernel_stats.csv")))[-1]
+        calls = dur = 0.0
+        frames = None
+        for row in csv.DictReader(open(path)):
+            name = row.get("Name") or row.get("KernelName") or ""
+            n, tot = float(row.get("Calls", 0) or 0), float(row.get("TotalDurationNs", 0) or 0)
+            if "gemm_nt_split_kernel<2, 4," in name:     # the 256x256 and 192x256 tile instantiations
+                calls += n
+                dur += tot
+            if "im2col_tiled_kernel" in name:
+                frames = n       # one patch gather per frame
+        if not calls or not frames:
+            return None
+        flops = GEMM_BIGTILE_FLOP_PER_FRAME * frames
+        ach = flops / (dur * 1e-9) / 1e12
+        return {"file": os.path.basename(path), "achieved": ach, "frac": ach / (PEAK_F16_MFMA_TFLOPS / 3.0),
+                "launches": int(calls), "frames": frames, "avg_launch_ms": dur / calls * 1e-6}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,11 +266,23 @@ def main():
                     help="at most this many frames inside a GPU phase at a time (0 = unlimited)")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="frames of the un-overlapped kernel-timing pass run after the timed region")
-    ap.add_argument("--frame-pool", type=int, default=8,
-                    help="distinct synthetic frames kept resident per rank (frame f uses slot f %% pool)")
+    ap.add_argument("--frame-pool", type=int, default=24,
+                    help="distinct synthetic frames kept resident per rank, 1.11 GB each (the rank's i-th frame uses "
+                         "slot i %% pool; with --steps <= pool every frame of the job is distinct)")
+    ap.add_argument("--dry-dist", action="store_true",
+                    help="no GPU work: launch / rendezvous (gloo) / shard / barrier / all-gather / one JSON line only")
+    ap.add_argument("--no-numa-bind", action="store_true",
+                    help="N > 1: do not pin a rank's threads to its GPU's NUMA node share of the host cores")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "12")),
                     help="frames in flight per GPU (host rANS of one frame overlaps GPU work of the others)")
     args = ap.parse_args()
+
+    force_launch = os.environ.get("CRA5_FORCE_SELF_LAUNCH") == "1"    # tests: the launcher path on a 1-GPU box
+    if (args.gpus > 1 or force_launch) and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it for N = 1: become the launcher of N ranks
+        raise SystemExit(self_launch(args.gpus))
+    if args.dry_dist:
+        return dry_dist(args)
 
     from cra5_amd import dist as D
     from cra5_amd import ops, synth
@@ -198,13 +296,19 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only product path")
     rank, world, local = D.init_from_env("cuda")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    numa = None
     if world > 1:
-        # N ranks share the node's host cores: keep every rank's torch CPU pool (weight preparation, the few host-side
-        # tensor ops of a frame) to its share instead of N pools of one thread per core each
-        torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
+        # N ranks share the node's host cores.  Pin this rank (its frame threads, its rANS work, its torch CPU pool)
+        # to its GPU's NUMA node, an equal share of that node's cores per rank on the node: pinned staging buffers
+        # are then allocated node-local and 8 x 12 frame threads do not migrate over both sockets.
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if not args.no_numa_bind:
+            numa = D.bind_rank_to_numa(local, n_local)
+        share = len(os.sched_getaffinity(0)) if (numa and numa.get("bound")) else (os.cpu_count() or 8) // world
+        torch.set_num_threads(max(1, share // 2))
 
     net = vaeformer_pretrained(quality=args.quality, pretrained=False)
     synth.load_synthetic(net, seed=7)
@@ -213,7 +317,9 @@ def main():
     # BASELINE.json configs[3]: the job's frames f = 0 .. world*K-1 are x_f ~ N(0,1) with seed 1000 + f,
     # rank r owns the contiguous block dist.shard_frames gives it ([8r, 8r+8) of 64 at K = 8).  They are
     # generated on the device and resident in HBM before the timed region; at most --frame-pool distinct
-    # frames are kept per rank (1.11 GB each), frame f re-using pool slot (f - first) % pool.
+    # frames are kept per rank (1.11 GB each): the rank's i-th frame is the tensor of seed
+    # 1000 + first + (i % pool) - with K <= pool (the driver's K = 20) every frame is its own tensor; beyond that the
+    # tensors repeat and the JSON line says so (`config.distinct_frames_per_rank`, `frame_seeds`).
     my_frames = D.shard_frames(world * args.steps, rank, world)
     pool = max(1, min(args.frame_pool, len(my_frames)))
     gdev = torch.Generator(device=dev)
@@ -221,6 +327,7 @@ def main():
     for i in range(pool):
         gdev.manual_seed(1000 + my_frames[0] + i)
         frames.append(torch.randn((1, C, 721, 1440), generator=gdev, device=dev, dtype=torch.float32))
+    seed_of_step = [1000 + my_frames[0] + (i % pool) for i in range(len(my_frames))]
 
     from cra5_amd.pipeline import FramePipeline
     pipe = FramePipeline(net, workers=args.inflight, device=dev)
@@ -300,11 +407,18 @@ def main():
             "f16 operands / fp32 accumulate in g_a,g_s (reduced precision, configs[4]); hyper-prior fp32-accurate"),
         "data": "synthetic",
         "config": {"workload": f"quality={C} single-frame full encode->bin->decode round trip per step "
-                               f"(BASELINE.json configs[2]); 1 frame/rank/step; frames f = 0..{world * args.steps - 1} "
-                               f"(x_f ~ N(0,1), seed 1000+f, configs[3]'s set) block-sharded over ranks",
+                               f"(BASELINE.json configs[2]); 1 frame/rank/step; job frames f = 0..{world * args.steps - 1} "
+                               f"block-sharded over ranks; " + (
+                                   "every frame its own tensor x_f ~ N(0,1), seed 1000+f (configs[3]'s set)"
+                                   if pool >= len(my_frames) else
+                                   f"{pool} distinct tensors per rank (x ~ N(0,1), seeds 1000+first+(i % {pool})) REUSED "
+                                   f"round-robin by the rank's {len(my_frames)} frames"),
                    "frame": [C, 721, 1440], "weights": "deterministic synthetic (cra5_amd/synth.py seed 7)",
                    "parallelism": f"frame-sharded x{world}, weights replicated",
-                   "frames_in_flight_per_gpu": args.inflight},
+                   "distinct_frames_per_rank": pool, "frame_seeds_rank0": [seed_of_step[0], seed_of_step[-1]],
+                   "frames_in_flight_per_gpu": args.inflight,
+                   "host": {"frame_threads_total": args.inflight * world, "host_threads": os.cpu_count(),
+                            "numa_bind_rank0": numa, "self_launched": os.environ.get("CRA5_SELF_LAUNCHED") == "1"}},
         "warmup_settle_frames": settle_frames,
         "collectives": {"initialized": bool(torch.distributed.is_available() and torch.distributed.is_initialized()),
                         "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
@@ -396,6 +510,10 @@ def main():
         ops.TIMER = None
         result.update(roofline_from(t2.summary(), max(1, args.roofline_steps)))
         if "roofline" in result:
+            rp = rocprof_gemm_frac()
+            if rp:   # the committed rocprofv3 summary of this command beside the live HIP-event figure
+                result["roofline"]["frac_rocprof"] = rp["frac"]
+                result["roofline"]["rocprof"] = rp
             result["roofline"]["measured_over"] = (
                 f"a separate un-overlapped pass of {max(1, args.roofline_steps)} frames run right after the timed "
                 "region (HIP events around every launch, on the launch stream, exclusive GPU phases); "
@@ -405,6 +523,14 @@ def main():
         try:
             result["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(
                 args.quality, cpu_threads)
+            if result["cpu_baseline"].get("extrapolated"):
+                import glob
+                full = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_full.json")))
+                if full:
+                    cb = json.load(open(full[-1])).get("cpu_baseline", {})
+                    result["cpu_baseline"]["whole_frame_committed"] = {
+                        "file": "profiles/" + os.path.basename(full[-1]), "value": cb.get("value"),
+                        "unit": "frames/s", "cores": cb.get("cores"), "sample": cb.get("sample")}
         except Exception as e:  # noqa: BLE001
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

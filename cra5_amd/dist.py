@@ -37,6 +37,84 @@ def init_from_env(device_type="cuda"):
     return rank, world, local
 
 
+def _parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_node(local):
+    """NUMA node of GPU `local` from its PCI address (sysfs), or None when it cannot be told."""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        return node if node >= 0 else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def rank_cpu_set(local, n_local, node=None, node_peers=None, allowed=None, node_cpus=None):
+    """The host CPUs rank `local` of `n_local` ranks on this node should run its frame threads and rANS
+    work on.  With a known NUMA node: that node's CPUs, cut into equal contiguous shares among the
+    `node_peers` = (index of this rank among the ranks on the same node, how many there are).  Without:
+    an equal contiguous share of the allowed CPUs.  Pure function of its arguments (tested on CPU)."""
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    cpus = allowed
+    k, m = local, n_local
+    if node is not None and node_cpus:
+        on_node = [c for c in node_cpus if c in set(allowed)]
+        if on_node:
+            cpus = on_node
+            k, m = node_peers if node_peers else (0, 1)
+    m = max(1, m)
+    if len(cpus) < m:
+        return cpus
+    # A node's list is "cores..., SMT siblings..." (EPYC: 0-63,128-191): take the k-th share of EVERY contiguous
+    # run, so that a rank gets whole cores (a core and its sibling) instead of sharing cores with another rank
+    runs, cur = [], [cpus[0]]
+    for c in cpus[1:]:
+        if c == cur[-1] + 1:
+            cur.append(c)
+        else:
+            runs.append(cur)
+            cur = [c]
+    runs.append(cur)
+    out = []
+    for r in runs:
+        share = len(r) // m
+        out.extend(r[k * share:(k + 1) * share] if share else [])
+    return out or cpus[k * (len(cpus) // m):(k + 1) * (len(cpus) // m)]
+
+
+def bind_rank_to_numa(local, n_local):
+    """Pin this process (all its future threads: the 12 frame threads, the rANS pool) to the CPUs of its
+    GPU's NUMA node, shared equally with the other ranks whose GPU sits on the same node.  Returns a dict
+    describing what was done (reported in bench.py's JSON line)."""
+    info = {"numa_node": None, "cpus": None, "bound": False}
+    try:
+        nodes = [gpu_numa_node(i) for i in range(n_local)]
+        node = nodes[local]
+        node_cpus = None
+        peers = None
+        if node is not None:
+            node_cpus = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+            same = [i for i in range(n_local) if nodes[i] == node]
+            peers = (same.index(local), len(same))
+        cpus = rank_cpu_set(local, n_local, node, peers, None, node_cpus)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info.update(numa_node=node, cpus=len(cpus), bound=True, first_cpu=cpus[0], last_cpu=cpus[-1])
+    except Exception as e:  # noqa: BLE001
+        info["error"] = repr(e)
+    return info
+
+
 def shard_frames(n_frames, rank, world):
     """Contiguous block partition: rank r owns frames [lo, hi). 64 frames on 8 GPUs ->
     [8r, 8r+8).  Remainders go to the lowest ranks."""

@@ -65,13 +65,15 @@ class KernelTimer:
         with self._lock:
             records, self.records = self.records, {}
         for kind, recs in records.items():
-            ms_tot, work = 0.0, 0.0
+            ms_tot, work, done = 0.0, 0.0, []
             for s, e, w in recs:
                 ms = ctypes.c_float()
                 check(lib().cra5_event_elapsed_ms(s, e, ctypes.byref(ms)), "cra5_event_elapsed_ms")
                 ms_tot += ms.value
                 work += w
-                self._free += [s, e]
+                done += [s, e]
+            with self._lock:       # frame threads pop from _free concurrently (_ev)
+                self._free += done
             out[kind] = dict(launches=len(recs), work=work, ms=ms_tot)
         return out
 

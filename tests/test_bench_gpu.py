@@ -48,3 +48,20 @@ def test_bench_under_torchrun_rccl_single_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert d["collectives"]["backend"] == "nccl" and d["collectives"]["initialized"] is True
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_rccl_single_rank():
+    """`python bench.py --gpus N` with no launcher (the driver's call): bench.py becomes the launcher.  On the
+    1-GPU box the path is forced for N = 1 (CRA5_FORCE_SELF_LAUNCH) with RCCL initialised (CRA5_FORCE_DIST)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--settle-batches", "0", "--roofline-steps", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(CRA5_FORCE_DIST="1", CRA5_FORCE_SELF_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert d["collectives"]["backend"] == "nccl" and d["config"]["host"]["self_launched"] is True
