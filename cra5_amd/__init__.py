@@ -44,7 +44,7 @@ def install_dropin():
     mod("cra5.models")
     mod("cra5.models.compressai")
     mod("cra5.models.compressai.zoo", vaeformer_pretrained=zoo.vaeformer_pretrained,
-        bmshj2018_factorized=zoo.bmshj2018_factorized, bmshj2018_hyperprior=zoo.bmshj2018_hyperprior,
-        mbt2018_mean=zoo.mbt2018_mean)
+        bmshj2018_factorized=zoo.bmshj2018_factorized, bmshj2018_factorized_relu=zoo.bmshj2018_factorized_relu,
+        bmshj2018_hyperprior=zoo.bmshj2018_hyperprior, mbt2018_mean=zoo.mbt2018_mean)
     mod("cra5.models.vaeformer")
     mod("cra5.models.vaeformer.vaeformer", VAEformer=vaeformer.VAEformer)

@@ -396,7 +396,10 @@ extern "C" int cra5_small_gemm_nt_split(const uint16_t *A, int lda_kp, const uin
   return launch_small<TN, KS, D, false>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, ps, st)
   const long tiles1 = (long)((M + 31) / 32) * ((N + 31) / 32);
   const int nk = Kp / 32;
-  // CRA5_HY_GEMM = "TN KS" forces an instantiation (tools/hyper_gemm_sweep.py)
+  // The instantiation is a function of the SHAPE only: it fixes the split-K factor and with it the fp32 summation
+  // order of h_s, which encoder and decoder must share bit for bit.  The sweep override (CRA5_HY_GEMM = "TN KS",
+  // tools/hyper_gemm_sweep.py) exists only in -DCRA5_HY_SWEEP builds (tools/build_variant.sh), never in the product.
+#ifdef CRA5_HY_SWEEP
   static const int forced = [] {
     const char *e = getenv("CRA5_HY_GEMM");
     int tn = 0, ks = 0;
@@ -414,6 +417,7 @@ extern "C" int cra5_small_gemm_nt_split(const uint16_t *A, int lda_kp, const uin
     case 401: HY_GO(4, 1, 2);
     default: break;
   }
+#endif
   // Measured on MI355X.  Warm micro-benchmark per shape (tools/hyper_gemm_sweep.sh, kernel us, this kernel vs the
   // LDS-tiled engine at a fixed 64 / 128 tile): 648x360x4096 34 vs 65, 648x360x1440 15.1 vs 16.2, 648x1080x360
   // 13.2 vs 8.6, 648x1440x360 16.1 vs 9.1, 648x8192x360 60 vs 26.  IN SITU (every GEMM of h_s meets weights that

@@ -2,9 +2,12 @@
 // row = [chunk 0: 32 hi halves | 32 lo halves][chunk 1: ...]; x = hi + lo, hi = f16(x),
 // lo = f16(x - hi).
 //
-// Range: f16 tops out at 65 504.  The value is SATURATED there before the split (one v_med3 per
+// Range: f16 tops out at 65 504.  A FINITE value is SATURATED there before the split (one v_med3 per
 // element), so an out-of-range activation degrades to +-65 504 instead of hi = inf, lo = -inf ->
-// NaN products.  Builds with
+// NaN products.  NON-FINITE values stay non-finite: v_med3 alone would turn NaN into -65 504 and +-inf into
+// +-65 504 (it returns min3 when an operand is NaN), i.e. a blown-up frame into finite garbage that no isfinite()
+// probe downstream can see; `fma(v, 0, med3(v))` adds v * 0 = NaN for NaN / inf and +-0 otherwise (one VALU).
+// Builds with
 // -DCRA5_RANGE_CHECK (python -m cra5_amd.build --flavour rangecheck) additionally count, per
 // producer call site, the elements with |x| >= 65 504 and the non-finite ones
 // (cra5_debug_range_counts in the C ABI): the evidence that a checkpoint's activations stay
@@ -38,9 +41,14 @@ __device__ __forceinline__ void cra5_range_probe(float) {}
 #define CRA5_RANGE_TU(name)
 #endif
 
+// saturate finite values to the f16 range, keep NaN / inf non-finite (NaN)
+__device__ __forceinline__ float cra5_sat(float v) {
+  return __builtin_fmaf(v, 0.0f, __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f));
+}
+
 __device__ __forceinline__ void cra5_split(float v, _Float16 &hi, _Float16 &lo) {
   cra5_range_probe(v);
-  const float vc = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+  const float vc = cra5_sat(v);
   hi = (_Float16)vc;
   lo = (_Float16)(vc - (float)hi);
 }
@@ -54,7 +62,7 @@ __device__ __forceinline__ void cra5_split_pair(float a, float b, unsigned &hi2,
   typedef _Float16 half2v __attribute__((ext_vector_type(2)));
   cra5_range_probe(a);
   cra5_range_probe(b);
-  const float ac = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), bc = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
+  const float ac = cra5_sat(a), bc = cra5_sat(b);
   const half2v h2 = {(_Float16)ac, (_Float16)bc};
   hi2 = __builtin_bit_cast(unsigned, h2);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CRA5_PLAIN_SPLIT)

@@ -50,7 +50,11 @@ def load_pretrained(state_dict):
     return {rename_key(k): v for k, v in state_dict.items()}
 
 
-def _find_checkpoint(quality):
+def _find_checkpoint(architecture, quality):
+    """$CRA5_WEIGHTS / the hub cache hold VAEformer checkpoints only: the CNN architectures have no published
+    weights in the reference either (zoo/image.py:290 raises for them)."""
+    if architecture != "vaeformer-pretrained":
+        return None
     cands = [os.environ.get("CRA5_WEIGHTS")]
     name = _CKPT_NAMES.get(quality)
     if name:
@@ -67,7 +71,7 @@ def _load_model(architecture, metric, quality, pretrained=False, progress=True, 
     if quality not in cfgs[architecture]:
         raise ValueError(f'Invalid quality value "{quality}"')
     if pretrained:
-        path = _find_checkpoint(quality) if metric == "mse" else None
+        path = _find_checkpoint(architecture, quality) if metric == "mse" else None
         if path is None:
             raise RuntimeError("Pre-trained model not yet available")
         state_dict = torch.load(path, map_location="cpu")

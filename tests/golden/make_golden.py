@@ -184,8 +184,10 @@ def stage_small():
     print("small done")
 
 
-def run_e2e(net, x, yhat_synth, step_lat, step_img, tag):
-    """All stages of the reference path on `x`; returns dict of sub-sampled arrays."""
+def run_e2e(net, x, yhat_synth, step_lat, step_img, tag, full_ints=False):
+    """All stages of the reference path on `x`; returns dict of sub-sampled arrays.
+    full_ints: also keep EVERY CDF index (int8) and y symbol (int16), so that a consumer can compare the
+    integer side element by element instead of through histograms."""
     o = {}
     t0 = time.time()
     moments = net.quant_conv(net.g_a(x))
@@ -218,6 +220,11 @@ def run_e2e(net, x, yhat_synth, step_lat, step_img, tag):
     o["sym_sub"] = sub(sym, step_lat).astype(np.int32)
     o["sym_hist"] = np.bincount((sym.reshape(-1).numpy() + 256).clip(0, 512), minlength=513)
     o["y_hat_sub"] = sub(y_hat, step_lat)
+    if full_ints:
+        o["idx_full"] = idx.reshape(-1).numpy().astype(np.int8)
+        o["sym_full"] = sym.reshape(-1).numpy().astype(np.int16)
+        assert np.array_equal(o["sym_full"].astype(np.int64), sym.reshape(-1).numpy().astype(np.int64))
+        o.update(margins(net, y, z, scales, means))
     o["bits_y"] = np.array([float((-torch.log2(y_lik)).sum())])
     o["bits_z"] = np.array([float((-torch.log2(z_lik)).sum())])
     t0 = time.time()
@@ -254,6 +261,93 @@ def synth_yhat(latent, seed):
 def synth_zhat(cz, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.round(3.0 * torch.randn(1, cz, 18, 36, generator=g))
+
+
+def margins(net, y, z, scales, means):
+    """How far the reference's own values sit from the nearest rounding / table boundary: the float error another
+    implementation may have on z, y - mu and sigma before ONE integer of the frame differs."""
+    med = net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+
+    def half_dist(v):
+        v = v.double()
+        return float((v - torch.floor(v) - 0.5).abs().min())
+    table = net.gaussian_conditional.scale_table.double()
+    sg = scales.double().reshape(-1, 1)
+    m_s = float((sg - table[:-1].reshape(1, -1)).abs().min())
+    return {"margin_z": np.array([half_dist(z - med)]), "margin_y": np.array([half_dist(y - means)]),
+            "margin_scale": np.array([m_s])}
+
+
+def stage_thin_search(seeds=range(100, 164)):
+    """Pick the input seed of the SECOND thin fixture (thin_e2e_b.npz).  round() and the scale-table search make the
+    integer side discontinuous: another implementation agrees with the reference on EVERY z symbol, CDF index and y
+    symbol of a frame only if its float error stays below the frame's margins (`margins`).  With 165 888 latents the
+    smallest margin of a random frame is ~1e-6 - the size of fp32 noise itself (thin_e2e.npz's frame: the product
+    flips 1 index).  This stage runs the reference on 64 candidate frames and prints their margins; the fixture
+    uses the seed with the widest one (`THIN_B_SEED`), so that byte equality with the reference-written stream and
+    cross-implementation decode can be asserted instead of x-failed."""
+    net = build_thin()
+    load_synth(net, seed=7)
+    best = None
+    for sd in seeds:
+        x = synth.synth_frame(8, seed=sd).unsqueeze(0)
+        moments = net.quant_conv(net.g_a(x))
+        y = moments[:, : moments.shape[1] // 2]
+        z = net.h_a(y)
+        z_hat, _ = net.entropy_bottleneck(z)
+        scales, means = net.h_s(z_hat).chunk(2, 1)
+        m = margins(net, y, z, scales, means)
+        worst = min(float(m["margin_z"][0]) / 4, float(m["margin_y"][0]), float(m["margin_scale"][0]))
+        print(f"seed {sd}: margin z {m['margin_z'][0]:.2e}  y {m['margin_y'][0]:.2e}  scale {m['margin_scale'][0]:.2e}"
+              f"  -> score {worst:.2e}", flush=True)
+        if best is None or worst > best[0]:
+            best = (worst, sd)
+    print("best seed", best[1], "score", best[0])
+
+
+def stage_thin_cands(seeds=None):
+    """Scratch fixtures (tests/golden/_cand/, git-ignored) with the reference's full integer side for a few candidate
+    seeds: tools/thin_seed_probe.py counts the product's disagreements with each on the GPU box."""
+    seeds = seeds or [int(v) for v in os.environ.get("THIN_CANDS", "").split(",") if v]
+    net = build_thin()
+    load_synth(net, seed=7)
+    os.makedirs(os.path.join(HERE, "_cand"), exist_ok=True)
+    for sd in seeds:
+        x = synth.synth_frame(8, seed=sd).unsqueeze(0)
+        moments = net.quant_conv(net.g_a(x))
+        y = moments[:, : moments.shape[1] // 2]
+        z = net.h_a(y)
+        med = net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+        z_sym = net.entropy_bottleneck.quantize(z, "symbols", med)
+        z_hat, _ = net.entropy_bottleneck(z)
+        scales, means = net.h_s(z_hat).chunk(2, 1)
+        idx = net.gaussian_conditional.build_indexes(scales)
+        sym = net.gaussian_conditional.quantize(y, "symbols", means)
+        np.savez_compressed(os.path.join(HERE, "_cand", f"thin_cand_{sd}.npz"), z_sym=z_sym.numpy().astype(np.int32),
+                            idx_full=idx.reshape(-1).numpy().astype(np.int8),
+                            sym_full=sym.reshape(-1).numpy().astype(np.int16), **margins(net, y, z, scales, means))
+        print("cand", sd, flush=True)
+
+
+THIN_B_SEED = 162   # widest margins of the 64 candidates (z 2.3e-4, y 4.5e-6, scale 2.1e-6); product: 0 flips (tools/thin_seed_probe.py, round 3: 10 of 16 candidates had none)
+
+
+def stage_thin2():
+    net = build_thin()
+    load_synth(net, seed=7)
+    x = synth.synth_frame(8, seed=THIN_B_SEED).unsqueeze(0)
+    o = run_e2e(net, x, synth_yhat(16, 5), step_lat=37, step_img=1009, tag="thin_b", full_ints=True)
+    o["x_seed"] = np.array([THIN_B_SEED])
+    for k in ("xhat_sub", "xhat_stats", "xhat_row10_c0", "xhat_row720_c0", "hs_synth_sub", "hs_synth_stats",
+              "hs_synth_idx_hist"):
+        o.pop(k, None)       # input-independent: already in thin_e2e.npz
+    # the reference's own decode of its own stream (x_hat from the .bin): what a cross-implementation decode must hit
+    out = net.compress(x)
+    assert out["strings"][0][0] == o["y_string"].tobytes() and out["strings"][1][0] == o["z_string"].tobytes()
+    rec = net.decompress(out["strings"], out["z_shape"])
+    o["xhat_rt_sub"] = sub(rec["x_hat"], 1009)
+    np.savez_compressed(os.path.join(HERE, "thin_e2e_b.npz"), **o)
+    print("thin2 done")
 
 
 def stage_thin():
@@ -310,6 +404,25 @@ def stage_full159():
     # end to end on the reference's own quantised latent: x_hat(y_hat(x)) sub-sampled
     _, y_hat, _ = net.encode_latent(x, type='quantized')
     o["y_hat_sub"] = sub(y_hat, 499)
+    # the integer side of that quantised latent (round 3): with z symbols and CDF indexes on record a consumer can tell
+    # a rounding flip of z (which moves every mu by ~1e-3 through h_s) from an error of its h_s
+    z = net.h_a(y)
+    o["z_sub"], o["z_stats"] = sub(z, 13), stats(z)
+    med = net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+    z_sym = net.entropy_bottleneck.quantize(z, "symbols", med).numpy().astype(np.int32)
+    o["z_sym_hist"] = np.bincount((z_sym.reshape(-1) + 64).clip(0, 128), minlength=129)
+    o["z_sym"] = z_sym.reshape(-1).astype(np.int16)
+    z_hat, _ = net.entropy_bottleneck(z)
+    scales, means = net.h_s(z_hat).chunk(2, 1)
+    o["scales_sub"], o["means_sub"] = sub(scales, 499), sub(means, 499)
+    idx = net.gaussian_conditional.build_indexes(scales)
+    o["idx_sub"] = sub(idx, 499).astype(np.int32)
+    o["idx_hist"] = np.bincount(idx.reshape(-1).numpy(), minlength=64)
+    sym = net.gaussian_conditional.quantize(y, "symbols", means)
+    o["sym_sub"] = sub(sym, 499).astype(np.int32)
+    o["sym_hist"] = np.bincount((sym.reshape(-1).numpy() + 256).clip(0, 512), minlength=513)
+    assert torch.equal(y_hat, sym.float() + means)
+    o.update(margins(net, y, z, scales, means))
     np.savez_compressed(os.path.join(HERE, "full159.npz"), **o)
     sk = json.load(open(os.path.join(HERE, "state_keys.json")))
     sk["v159"] = {k: list(v) for k, v in shapes.items()}
@@ -468,6 +581,6 @@ if __name__ == "__main__":
     ap.add_argument("--stage", nargs="+", default=["small", "thin"])
     a = ap.parse_args()
     for s in a.stage:
-        dict(small=stage_small, thin=stage_thin, full=stage_full, full159=stage_full159, stats=stage_stats,
+        dict(small=stage_small, thin=stage_thin, thin_search=stage_thin_search, thin_cands=stage_thin_cands, thin2=stage_thin2, full=stage_full, full159=stage_full159, stats=stage_stats,
              cnn=stage_cnn, cnn_relu=stage_cnn_relu,
              thin64=lambda: stage_fp64("thin"), full64=lambda: stage_fp64("full"))[s]()

@@ -59,8 +59,9 @@ def test_block_pattern():
 
 
 def test_from_state_dict_and_buffer_resize():
-    """vaeformer.py:168-185 + models/base.py:69-89: `backbone.` prefix stripped,
-    kl_loss.logvar dropped, empty CDF buffers resized to the checkpoint's."""
+    """models/base.py:69-89: `load_state_dict` resizes the empty CDF buffers to the checkpoint's (thin model).
+    The `backbone.` prefix / `kl_loss.logvar` / rename_key handling of the full `pretrained=True` route
+    (vaeformer.py:168-185, zoo/pretrained.py:36-64) is tested in tests/test_checkpoint_route.py."""
     thin = VAEformer(0, **synth.thin_model_kwargs())
     synth.load_synthetic(thin, seed=1)
     sd = thin.state_dict()

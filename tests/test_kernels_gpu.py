@@ -451,6 +451,10 @@ def test_split_f16_range_guard(dev):
     # logits of +-3e5: the softmax is one-hot and an ulp of a logit moves whole rows -> 1e-4-class, finite
     assert res["attention_x200"]["rel_rmse"] < 1e-3
     assert res["model_thin"]["counts"] == [0, 0] and res["model_thin"]["finite"]
+    # NaN / inf are NOT saturated: they reach the outputs (v_med3 alone turned NaN into -65504)
+    nf = res["nonfinite"]
+    assert nf["split_keeps"] and nf["gemm_rows"] and nf["gemm_split_rows"] and nf["layernorm_rows"], nf
+    assert nf["counts"][1] >= 2     # and the rangecheck flavour counts them as non-finite events
 
 
 @pytest.mark.parametrize("M,N,K", [(648, 1080, 360), (648, 360, 360), (648, 1440, 360), (648, 360, 1440),

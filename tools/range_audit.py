@@ -64,6 +64,32 @@ def main():
         res[name] = dict(split_in=c_in, gemm_out=c_out, layernorm=c_ln, gemm_rel_rmse=rel(out, ref),
                          gemm_finite=bool(torch.isfinite(out).all()), ln_finite=bool(torch.isfinite(ln).all()),
                          ln_rms=float(ln.pow(2).mean().sqrt()))
+    # non-finite values must STAY non-finite through every split producer (a NaN that v_med3 turned into -65504
+    # would make a blown-up frame look healthy to every isfinite() probe downstream): one NaN and one inf in the
+    # activations -> the split copy, the GEMM output row (fp32 and split) and the LayerNorm row are non-finite,
+    # every other row stays finite
+    xn = a0.clone()
+    xn[3, 17] = float("nan")
+    xn[900, 5] = float("inf")
+    xn = xn.to(dev)
+    sa = ops.split_f16(xn)
+    back = sa.to_float()
+    out_s = ops.SplitMat.empty(M, N, dev, zero=True)
+    out = ops.gemm_nt_split(sa, sw, out_split=out_s)
+    sm = ops.SplitMat.empty(M, K, dev)
+    ops.layernorm(xn, torch.ones(K, device=dev), torch.zeros(K, device=dev), 1e-6, out_split=sm, want_f32=False)
+    ln = sm.to_float()
+    bad_rows = torch.zeros(M, dtype=torch.bool, device=dev)
+    bad_rows[3] = bad_rows[900] = True
+
+    def rows_nonfinite(t):
+        return (~torch.isfinite(t)).any(dim=1)
+    res["nonfinite"] = dict(
+        split_keeps=bool(not torch.isfinite(back[3, 17]) and not torch.isfinite(back[900, 5])
+                         and int((~torch.isfinite(back)).sum()) == 2),
+        gemm_rows=bool(torch.equal(rows_nonfinite(out), bad_rows)),
+        gemm_split_rows=bool(torch.equal(rows_nonfinite(out_s.to_float()), bad_rows)),
+        layernorm_rows=bool(torch.equal(rows_nonfinite(ln), bad_rows)), counts=counts())
     # attention on large-magnitude q/k/v (head dim 64): softmax must stay finite, outputs bounded by max|v|
     qkv = torch.randn(576, 3 * 128, generator=g) * 200.0
     qs = ops.split_f16(qkv.to(dev))
