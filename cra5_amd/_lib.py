@@ -73,6 +73,8 @@ SIGNATURES = {
     "cra5_event_record": (c_int, [c_void_p, c_void_p]),
     "cra5_event_elapsed_ms": (c_int, [c_void_p, c_void_p, P(c_float)]),
     "cra5_event_destroy": (c_int, [c_void_p]),
+    "cra5_copy_h2d_staged": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
+    "cra5_copy_d2h_staged": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
     "cra5_debug_range_counts": (c_int, [P(ctypes.c_uint64), c_int]),
 }
 

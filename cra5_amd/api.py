@@ -14,7 +14,11 @@ out).  Conscious differences:
   * normalisation is fused into the patch gather and de-normalisation into the
     overlap-add store (one pass over the 1.1 GB frame instead of two);
   * the reference's `return_format='de_normlized'` default typo (returns None) is kept
-    as an accepted alias of 'de_normalized' rather than reproduced.
+    as an accepted alias of 'de_normalized' rather than reproduced;
+  * a frame with NaN / inf values raises ValueError at the encode edge (the reference would code `int(NaN)`
+    garbage silently; masked NetCDF values arrive as NaN);
+  * host arrays move through a pinned staging buffer in chunks (csrc/runtime.hip) instead of `.to(device)` /
+    `.cpu()`: `decode_from_bin(..., to_host=True | out=array)` returns the reconstruction as a host array.
 """
 import json
 import os
@@ -24,7 +28,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import binfmt
+from . import binfmt, ops
 from .zoo import vaeformer_pretrained
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -115,11 +119,32 @@ class cra5_api:
         return np.concatenate(one_step, 0).astype(np.float32, copy=False)
 
     def _frame(self, time_stamp, data):
+        """-> the frame as a float32 device tensor.  Host arrays go through this thread's pinned staging buffer
+        into this thread's persistent device frame buffer (chunked, host memcpy overlapped with the DMA): the
+        returned tensor is that buffer, valid until this thread's next call."""
         if data is None:
             data = self.read_data_from_nc(time_stamp)
-        if not isinstance(data, torch.Tensor):
-            data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
-        return data.to(self.device, dtype=torch.float32)
+        if isinstance(data, torch.Tensor):
+            if data.is_cuda or not self.net.device.type == "cuda":
+                return data.to(self.device, dtype=torch.float32)
+            data = data.detach().numpy()
+        if self.net.device.type != "cuda":
+            return torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(self.device)
+        arr = np.ascontiguousarray(data, dtype=np.float32)
+        pin = self.net._pinned("api_x_in", tuple(arr.shape), torch.float32)
+        xdev = self.net._buf("api_x_dev", tuple(arr.shape))
+        return ops.copy_h2d_staged(xdev, arr, pin)
+
+    @staticmethod
+    def _finite_probe(frame):
+        """One reduction pass over the frame, asynchronous: NaN / inf anywhere make the sum non-finite."""
+        return frame.sum(dtype=torch.float32)
+
+    @staticmethod
+    def _require_finite(probe):
+        if not bool(torch.isfinite(probe)):
+            raise ValueError("the input frame holds NaN / inf values (masked NetCDF values are read as NaN): fill them "
+                             "before encoding - the codec would turn them into arbitrary symbols")
 
     def channel_vname_mapping(self):
         """cra5_api.py:228-241."""
@@ -169,7 +194,9 @@ class cra5_api:
         """cra5_api.py:53-71."""
         frame = self._frame(time_stamp, data)
         with torch.no_grad():
+            probe = self._finite_probe(frame)
             y = self._encode_y(frame)
+            self._require_finite(probe)
             if latent_type == 'float':
                 return y.unsqueeze(0)
             if latent_type == 'quantized':
@@ -189,7 +216,9 @@ class cra5_api:
         frame = self._frame(time_stamp, data)
         st2 = time.time()
         with torch.no_grad():
+            probe = self._finite_probe(frame)
             y = self._encode_y(frame)
+            self._require_finite(probe)
             if return_format == 'latent':
                 return y.unsqueeze(0)
             if return_format == 'quantized':
@@ -317,7 +346,9 @@ class cra5_api:
             t1 = time.time()
             with torch.no_grad():
                 x = self._stage_in(arr)
+                probe = self._finite_probe(x)
                 y_str, z_str = self.net._compress_frame(x=x, mean=self._mean_flat, std=self._std_flat)
+                self._require_finite(probe)
             output = {"strings": [[y_str], [z_str]], "z_shape": torch.Size([self.net.Hz, self.net.Wz])}
             t2 = time.time()
             file_url = f'{save_root}/{ts.split("-")[0]}/{ts}.bin'
@@ -381,8 +412,9 @@ class cra5_api:
         with torch.no_grad():
             return self.net.decode_latent(y_hat)
 
-    def decode_from_bin(self, time_stamp=None, custom_path=None, return_format='de_normalized'):
-        """cra5_api.py:153-192."""
+    def decode_from_bin(self, time_stamp=None, custom_path=None, return_format='de_normalized', to_host=False, out=None):
+        """cra5_api.py:153-192.  `to_host=True` (or `out=` a float32 array of the frame's shape): `x_hat` comes back
+        as a HOST numpy array through the pinned staging buffer instead of a device tensor."""
         bin_path = custom_path or f'{self.local_root}/CRA5/{time_stamp[:4]}/{time_stamp}.bin'
         decoding_start = time.time()
         lstrings, shape = self._read_bin(bin_path)
@@ -398,5 +430,13 @@ class cra5_api:
                     x_hat = self.net._decode_frame(y_hat[0], mean=self._mean_flat, std=self._std_flat)
             else:
                 raise ValueError(f"unknown return_format {return_format!r}")
+            if to_host or out is not None:
+                src = x_hat.reshape(x_hat.shape[-3:]).contiguous()
+                if out is None:
+                    out = np.empty(tuple(src.shape), dtype=np.float32)
+                if out.dtype != np.float32 or tuple(out.shape) != tuple(src.shape) or not out.flags["C_CONTIGUOUS"]:
+                    raise ValueError("`out` must be a C-contiguous float32 array of shape %r" % (tuple(src.shape),))
+                pin = self.net._pinned("api_x_out", tuple(src.shape), torch.float32)
+                x_hat = ops.copy_d2h_staged(out, src, pin)
         torch.cuda.synchronize()
         return dict(x_hat=x_hat, decoding_time=time.time() - decoding_start)

@@ -295,6 +295,17 @@ int cra5_event_record(void *ev, void *stream);
 int cra5_event_elapsed_ms(void *start, void *stop, float *ms);
 int cra5_event_destroy(void *ev);
 
+/* Host <-> device frame copies through a caller-owned PINNED staging buffer of >= `bytes` (csrc/runtime.hip): the copy
+ * is cut into `chunk_bytes` chunks; `n_threads` host threads (the caller is one of them) memcpy chunk c + 1 between
+ * pageable and pinned memory while the DMA engine moves chunk c on `stream`.  Replaces the `.to(device)` / `.cpu()` of
+ * a 1.11 GB frame in cra5_api.py:81-125,153-192.  h2d: returns once every chunk has been handed to the stream (the
+ * device copy completes in stream order; `pinned` must stay untouched until then); d2h: returns when `dst_host` holds
+ * all bytes (the copies are queued behind whatever `stream` already holds). */
+int cra5_copy_h2d_staged(void *dst_dev, const void *src_host, void *pinned, size_t bytes, size_t chunk_bytes,
+                         int n_threads, void *stream);
+int cra5_copy_d2h_staged(void *dst_host, const void *src_dev, void *pinned, size_t bytes, size_t chunk_bytes,
+                         int n_threads, void *stream);
+
 /* Range audit of the split-f16 producers (csrc/split.h): out[0] = elements with |x| >= 65504 (clipped
  * by the saturating split), out[1] = non-finite elements, counted since the last reset by every
  * LayerNorm / GEMM-epilogue / attention / patch-gather store.  Only in the `rangecheck` build flavour
