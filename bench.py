@@ -271,6 +271,8 @@ def main():
                          "slot i %% pool; with --steps <= pool every frame of the job is distinct)")
     ap.add_argument("--dry-dist", action="store_true",
                     help="no GPU work: launch / rendezvous (gloo) / shard / barrier / all-gather / one JSON line only")
+    ap.add_argument("--no-api-sample", action="store_true",
+                    help="skip the reference-named single-frame API sample (`api_single_frame`, rank 0, N = 1)")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="N > 1: do not pin a rank's threads to its GPU's NUMA node share of the host cores")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "12")),
@@ -519,6 +521,35 @@ def main():
                 "region (HIP events around every launch, on the launch stream, exclusive GPU phases); "
                 "`roofline_timed_region` holds the sampled measurement taken inside the timed region, where "
                 "launches of concurrent frames overlap and per-launch durations are inflated")
+    if rank == 0 and world == 1 and not args.no_api_sample and args.quality == 268:
+        # What a drop-in caller of the REFERENCE-NAMED single-frame methods sees (test.py:14-45 in the reference):
+        # encode_era5_as_bin(host array -> .bin on disk) + decode_from_bin(.bin -> x_hat on the device), one frame at
+        # a time on one thread, PCIe-inclusive.  Outside the timed region; never part of `value`.
+        try:
+            import tempfile
+            from cra5_amd.api import cra5_api
+            net.gpu_exclusive = False
+            tmp = tempfile.mkdtemp(prefix="cra5_bench_")
+            api = cra5_api(local_root=tmp, device="cuda", weights=net)
+            host = (frames[0][0] * api.std + api.mean).cpu().numpy()      # physical units, pageable host memory
+            ts, te, td = "2024-06-01T00:00:00", [], []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                api.encode_era5_as_bin(ts, save_root=tmp + "/CRA5", data=host)
+                t1 = time.perf_counter()
+                api.decode_from_bin(ts, return_format="de_normalized")
+                td.append(time.perf_counter() - t1)
+                te.append(t1 - t0)
+            e, d = sorted(te[1:])[1], sorted(td[1:])[1]
+            result["api_single_frame"] = {
+                "value": 1.0 / (e + d), "unit": "frames/s", "encode_s": e, "decode_s": d, "threads": 1,
+                "what": "cra5_api.encode_era5_as_bin(data=host fp32 array) + decode_from_bin('de_normalized'), serial, "
+                        "H2D of the 1.11 GB frame and .bin write / read included, x_hat left on the device as the "
+                        "reference does (tools/api_testpy_loop.py times every call of the reference's test.py loop)"}
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+        except Exception as ex:  # noqa: BLE001
+            result["api_single_frame"] = {"value": None, "error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(

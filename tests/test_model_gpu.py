@@ -315,6 +315,24 @@ def test_api_surface_thin(thin, dev, tmp_path):
     ref = x_norm[0] * api.std + api.mean
     assert rmse(d2["x_hat"], ref) <= 1e-5
     assert api.decode_from_bin("2024-06-01T00:00:00", return_format='latent').shape == (1, 16, 72, 144)
+    # host arrays in / out through the chunked pinned staging (csrc/runtime.hip): same bits as the device path
+    fr_np = frame.numpy()
+    assert torch.equal(api._frame(None, fr_np).cpu(), frame)
+    assert torch.equal(api.encode_to_latent("2024-06-01T00:00:00", data=fr_np), y)
+    d3 = api.decode_from_bin("2024-06-01T00:00:00", return_format='de_normalized', to_host=True)
+    assert isinstance(d3["x_hat"], np.ndarray) and np.array_equal(d3["x_hat"], d2["x_hat"].reshape(8, 721, 1440).cpu().numpy())
+    buf = np.zeros((8, 721, 1440), dtype=np.float32)
+    assert api.decode_from_bin("2024-06-01T00:00:00", return_format='normalized', out=buf)["x_hat"] is buf
+    assert np.array_equal(buf, x_norm[0].cpu().numpy())
+    with pytest.raises(ValueError, match="C-contiguous float32"):
+        api.decode_from_bin("2024-06-01T00:00:00", out=np.zeros((8, 721, 1439), dtype=np.float32))
+    # a frame with a masked (NaN) value is refused at the encode edge instead of being coded as garbage
+    bad = fr_np.copy()
+    bad[3, 100, 200] = np.nan
+    with pytest.raises(ValueError, match="NaN / inf"):
+        api.encode_era5_as_bin("2024-06-01T00:00:00", save_root=str(tmp_path / "CRA5"), data=bad)
+    with pytest.raises(ValueError, match="NaN / inf"):
+        api.encode_to_latent("2024-06-01T00:00:00", data=bad)
 
 
 # --------------------------------------------------------------------------------------
