@@ -337,8 +337,14 @@ def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None, out_split=None
     return out if out is not None else out_split
 
 
-def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None, hi_only=False):
-    """qkv_s: SplitMat [H*W, 3C]; pad_s: SplitMat [1, 3C] (the split qkv bias)."""
+def attention_workspace_bytes(n_tokens, heads):
+    """Bytes of device workspace the balanced whole-grid attention schedule wants for this shape (0: none)."""
+    return int(lib().cra5_attention_workspace_bytes(int(n_tokens), int(heads)))
+
+
+def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None, hi_only=False, workspace=None):
+    """qkv_s: SplitMat [H*W, 3C]; pad_s: SplitMat [1, 3C] (the split qkv bias).  workspace: a device byte tensor
+    of >= attention_workspace_bytes(H*W, heads) -> the balanced schedule for whole-grid launches."""
     _devs(qkv_s.data, pad_s.data)
     _dev(out)
     N, C = qkv_s.rows, qkv_s.K // 3
@@ -347,10 +353,19 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
         assert out_split.rows == N and out_split.K == C
     scale = float((C // heads) ** -0.5)
     ev = TIMER.start() if TIMER is not None else None
-    check(lib().cra5_window_attention_split(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
-                                            _p(out_split.data) if out_split is not None else None,
-                                            out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
-                                            scale, int(bool(hi_only)), _stream()), "cra5_window_attention_split")
+    if workspace is not None:
+        assert workspace.is_cuda and workspace.is_contiguous()
+        check(lib().cra5_window_attention_split_ws(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
+                                                   _p(out_split.data) if out_split is not None else None,
+                                                   out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
+                                                   scale, int(bool(hi_only)), ctypes.c_void_p(workspace.data_ptr()),
+                                                   workspace.numel() * workspace.element_size(), _stream()),
+              "cra5_window_attention_split_ws")
+    else:
+        check(lib().cra5_window_attention_split(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
+                                                _p(out_split.data) if out_split is not None else None,
+                                                out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
+                                                scale, int(bool(hi_only)), _stream()), "cra5_window_attention_split")
     if ev is not None:
         TIMER.stop("window_attention_split", ev, 4.0 * N * (wh * ww) * C)
     return out if out is not None else out_split

@@ -262,6 +262,9 @@ class VAEformer(nn.Module):
         # (streams overlap: other frames' blocks fill the tail / epilogue gaps of a kernel)
         self.gpu_exclusive = os.environ.get("CRA5_GPU_EXCLUSIVE", "1") != "0"
         self.attn_mode = os.environ.get("CRA5_ATTN", "split")   # "split" (f16-MFMA, fp32-accurate) | "f32"
+        # whole-grid attention: balanced 12 + 8-wave passes + key-split leftover (csrc/attention_split_f16.hip, BAL);
+        # CRA5_ATTN_BALANCED=0 keeps the plain 27-work-groups-per-head launch (A/B runs)
+        self.attn_balanced = os.environ.get("CRA5_ATTN_BALANCED", "1") != "0"
         self.gemm_mode = os.environ.get("CRA5_GEMM", "split")
         if self.gemm_mode not in ("split", "f32"):
             raise ValueError("CRA5_GEMM must be 'split' or 'f32'")
@@ -462,7 +465,11 @@ class VAEformer(nn.Module):
             qkv_s = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out_name=f"qkv{D}")
             pad_s = self._derive("pad." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)))
             att = self._sbuf(f"att{D}", N, D, zero=True)
-            ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att,
+            ws = None
+            if blk.window is None and self.attn_balanced:
+                nb = ops.attention_workspace_bytes(N, blk.heads)     # 0: no balanced schedule for this shape
+                ws = self._buf("attn_ws", (nb,), torch.uint8) if nb else None
+            ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att, workspace=ws,
                                        hi_only=self.precision == "f16" and pre.startswith(("g_a.", "g_s.")))
             self._mm(att, pre + ".attn.proj", blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
             h = self._ln(t_out, blk.norm2, f"h{D}")

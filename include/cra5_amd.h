@@ -194,6 +194,18 @@ int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uin
                                 int H, int W, int wh, int ww, float scale, int hi_only,
                                 void *stream);
 
+/* The same call with a caller-owned device workspace (>= cra5_attention_workspace_bytes(H*W, heads) bytes, 16-byte
+ * aligned; 0 bytes = this shape has no balanced schedule).  With it, the whole-grid (global) launch runs the BALANCED
+ * schedule: every head gets CUs / heads work-group slots, a slot's query tiles run in passes of 12 + 8 waves (3 + 2
+ * per SIMD), and the few leftover query tiles are cut along the keys into per-slot ranges whose partial softmaxes a
+ * merge kernel combines in fixed order - 5.06 instead of 6 wave-tiles per SIMD on 256 CUs (vit_nlc.py:94-112).
+ * Without a workspace, for windowed shapes and where the plan does not apply it is cra5_window_attention_split. */
+size_t cra5_attention_workspace_bytes(int n_tokens, int heads);
+int cra5_window_attention_split_ws(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
+                                   float *out, uint16_t *out_split, int out_kp, int C, int heads,
+                                   int H, int W, int wh, int ww, float scale, int hi_only,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
 /* ============================ device: layout / conv edges ===================== */
 
 /* Patch gather for a strided Conv2d as GEMM (vit_nlc.py:302-308), fused with the API's

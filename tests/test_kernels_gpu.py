@@ -209,6 +209,46 @@ def test_window_attention_split_f16(dev, ws):
     assert e_split < 4e-6 and e_split <= 1.5 * e_f32 + 1e-8
 
 
+def test_global_attention_balanced_schedule(dev):
+    """The balanced whole-grid schedule (passes of 12 + 8 waves per work-group slot + key-split leftover tiles merged
+    by attention_merge_kernel) at the model's shape, 10 368 tokens x 16 heads: queries of the full passes run the SAME
+    key loop as the plain launch -> bit-identical; the 128 leftover queries per head (tokens 10 240..10 367) are
+    merged from 16 key ranges -> compared with float64, same accuracy class as the plain kernel."""
+    H, W, C, heads = 72, 144, 1024, 16
+    N = H * W
+    nb = ops.attention_workspace_bytes(N, heads)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    assert cus != 256 or nb == 16 * 4 * 16 * 32 * 68 * 4       # 256 CUs: 4 leftover tiles x 16 key ranges per head
+    if nb == 0:
+        pytest.skip(f"no balanced plan on a {cus}-CU device")
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(N, 3 * C, generator=g)
+    qkv[:, :2 * C] *= 1.7                                   # logits of a few units: a softmax that is not flat
+    qkv[777, C:2 * C] *= 3.0                                # ... and one dominant key
+    qs = ops.split_f16(qkv.to(dev))
+    pad = ops.split_f16(torch.zeros(1, 3 * C, device=dev))
+    plain = ops.window_attention_split(qs, pad, heads, H, W, H, W, out=torch.empty(N, C, device=dev))
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out = torch.full((N, C), float("nan"), device=dev)
+    out_s = ops.SplitMat.empty(N, C, dev, zero=True)
+    ops.window_attention_split(qs, pad, heads, H, W, H, W, out=out, out_split=out_s, workspace=ws)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()                                          # every token written exactly once
+    n_full = (N // 32 // (cus // heads)) * (cus // heads) * 32
+    assert torch.equal(out[:n_full], plain[:n_full])
+    tail = slice(n_full, N)
+    qd = qkv.double().view(N, 3, heads, 64)
+    q, k, v = qd[tail, 0].permute(1, 0, 2), qd[:, 1].permute(1, 0, 2), qd[:, 2].permute(1, 0, 2)
+    ref = (torch.softmax((q * 64 ** -0.5) @ k.transpose(-1, -2), -1) @ v).permute(1, 0, 2).reshape(N - n_full, C)
+    e_bal, e_plain = rmse(out[tail], ref), rmse(plain[tail], ref)
+    print(f"balanced global attention: leftover tokens rmse {e_bal:.2e} (plain kernel {e_plain:.2e})")
+    assert e_bal < 2e-6 and e_bal <= 1.5 * e_plain + 1e-8
+    assert rmse(out_s.to_float(), out) < 1e-6                                  # split output = fp32 output (22 bits)
+    # deterministic: the merge adds the key ranges in a fixed order
+    out2 = ops.window_attention_split(qs, pad, heads, H, W, H, W, out=torch.empty(N, C, device=dev), workspace=ws)
+    assert torch.equal(out2, out)
+
+
 def test_attention_split_softmax_spike(dev):
     """Late dominant key: forces the (exactly skipped / taken) online-softmax rescale branch."""
     H, W, C, heads = 8, 72, 64, 1

@@ -17,6 +17,15 @@ for name, (wh, ww) in (("global", (72, 144)), ("w24", (24, 24)), ("w12x48", (12,
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"split {name:8s}: {dt*1e3:8.3f} ms  {4.0*H*W*wh*ww*C/dt/1e12:7.1f} TF", flush=True)
 
+nb = ops.attention_workspace_bytes(H * W, heads)
+if nb:
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    for _ in range(2): ops.window_attention_split(qs, ps, heads, H, W, H, W, out_split=out_s, workspace=ws)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): ops.window_attention_split(qs, ps, heads, H, W, H, W, out_split=out_s, workspace=ws)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(f"split global balanced: {dt*1e3:8.3f} ms  {4.0*H*W*H*W*C/dt/1e12:7.1f} TF", flush=True)
+
 # hyper-prior shape: 18 x 36 tokens, 360-d, 5 heads x 72 (exact-f32 kernel)
 H2, W2, C2, h2 = 18, 36, 360, 5
 qkv2 = torch.randn(H2 * W2, 3 * C2, device=dev); b2 = torch.randn(3 * C2, device=dev)

@@ -69,31 +69,11 @@ constexpr int VS = 96;   // V LDS row stride (halves): 192 B - see the ds_read_b
 constexpr int MAX_WIN_TOKENS = 1152;   // windowed (not whole-grid) launches: L <= this (9 KB offset table: three 4-wave
                                         // work-groups of 52.7 KB each fit a CU's 160 KB)
 
-// Balanced schedule of the whole-grid (global) launch (BAL).  A wave owns 32 queries for the whole key loop and the
-// matrix pipe is per SIMD, so the unit of work is a (32-query tile, SIMD) pair: 10 368 tokens x 16 heads = 5184
-// wave-tiles on 1024 SIMDs = 5.06 each.  The plain launch (27 work-groups of 12 waves per head = 432 on 256 CUs) runs
-// two rounds of 3 waves per SIMD = 6 units, the second round on 176 of the 256 CUs.  Here every head gets `groups` =
-// CUs / heads work-group slots; slot c runs its `base` = T / groups wave-tiles in passes of NW (20 = 12 + 8: 3 + 2
-// waves per SIMD), and the `rem` = T - groups * base leftover tiles of a head (4) are cut along the KEYS into `groups`
-// ranges - 4-wave work-groups, one wave per SIMD, 1/16 of the key loop each - whose partial (m, l, O) a small merge
-// kernel combines in fixed order: 5 + 1/16 units instead of 6.
-struct BalArgs {
-  int groups;       // work-group slots per head
-  int base;         // full wave-tiles per slot
-  int n_wg_pass;    // heads * groups: work-groups per pass (mode 0) / per leftover chunk (mode 1)
-  int mode;         // 0: the full passes; 1: leftover tiles, keys split `groups` ways -> partials in ws
-  int rem_tile0;    // mode 1: first leftover wave-tile = groups * base
-  int rem;          // mode 1: leftover wave-tiles per head
-  float *ws;        // mode 1: partials [head][rem][groups][32][WS_ROW]
-};
-constexpr int WS_ROW = 68;   // floats per query of a partial: O[64], m, l, 2 pad (16-byte rows)
-
-template <int NW, bool HI, bool GLOBAL, bool BAL = false>
+template <int NW, bool HI, bool GLOBAL>
 __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void window_attention_split_kernel(
     const unsigned short *__restrict__ qkv, long ldq /* halves per row = 2*Kp */,
     const unsigned short *__restrict__ pad_row, float *__restrict__ out, unsigned short *__restrict__ out_s,
-    int Kp_out, int C, int heads, WinGeom g, int q_tiles, float scale, BalArgs bal) {
-  static_assert(!BAL || GLOBAL, "the balanced schedule is for whole-grid launches");
+    int Kp_out, int C, int heads, WinGeom g, int q_tiles, float scale) {
   constexpr int NT = NW * 64;
   constexpr int PIECES = 32 * 16;                 // 16-byte pieces per K (or V) tile
   constexpr int STG = (PIECES + NT - 1) / NT;
@@ -101,10 +81,19 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // [K hi][K lo] : 32 x KS ;  [V hi][V lo] : 32 x VS (row-major like K, transposed by the READ)
   constexpr int KPL = 32 * KS + 32;   // K plane stride (halves): +64 B so hi/lo planes hit different bank halves
   constexpr int VPL = 32 * VS;        // V plane stride
+#ifndef ATT_LDS_PAD
+#define ATT_LDS_PAD 0
+#endif
+#ifndef ATT_PRIO_PV
+#define ATT_PRIO_PV 0
+#endif
+#ifndef ATT_VALU_PER_MFMA
+#define ATT_VALU_PER_MFMA 12
+#endif
   // two K buffers and two V^T buffers: tile j+1's scores are issued to the matrix pipe BEFORE
   // the softmax of tile j, so K runs one tile ahead of V; one barrier per key tile.
   constexpr int KBUF = 2 * KPL, VBUF = 2 * VPL;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * KBUF + 2 * VBUF];
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * KBUF + 2 * VBUF + ATT_LDS_PAD];
   unsigned short *Ks = lds;
   unsigned short *Vt = lds + 2 * KBUF;
   // windowed launches: byte offset (from qkv) of every window token's row, pad tokens -> the pad
@@ -113,58 +102,42 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   __shared__ long long tab[TAB];
 
   const int L = g.wh * g.ww;
-  int head, win, tile0, n_active = NW, j0 = 0, j1 = L / 32, bal_c = 0;
-  if (BAL) {
-    // blockIdx order IS the schedule: all work-groups of pass 0 are dispatched before any of pass 1.  Inside a pass
-    // the work-groups of a head sit on ONE XCD (blockIdx % 8 selects the XCD: its K / V stay in that L2).
-    const int pass = blockIdx.x / bal.n_wg_pass, w = blockIdx.x - pass * bal.n_wg_pass;
-    int slot;
-    if ((heads & 7) == 0 && (bal.n_wg_pass & 7) == 0) {
-      const int xcd = w & 7, s_ = w >> 3;
-      head = xcd * (heads >> 3) + s_ / bal.groups;
-      slot = s_ % bal.groups;
-    } else {
-      head = w / bal.groups;
-      slot = w % bal.groups;
-    }
-    win = 0;
-    bal_c = slot;
-    if (bal.mode == 0) {
-      tile0 = slot * bal.base + pass * NW;
-      n_active = min(NW, bal.base - pass * NW);
-    } else {
-      tile0 = bal.rem_tile0 + pass * NW;                 // (leftover chunk `pass` of NW tiles)
-      n_active = min(NW, bal.rem - pass * NW);
-      j0 = (int)((long)(L / 32) * slot / bal.groups);
-      j1 = (int)((long)(L / 32) * (slot + 1) / bal.groups);
-    }
-  } else {
-    const int pid = xcd_remap(blockIdx.x, gridDim.x);
-    const int qt = pid % q_tiles;
-    const int wh_id = pid / q_tiles;
-    head = wh_id % heads;
-    win = wh_id / heads;
-    tile0 = qt * NW;
-  }
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = pid % q_tiles;
+  const int wh_id = pid / q_tiles;
+  const int head = wh_id % heads;
+  const int win = wh_id / heads;
   const int wr = win / g.nwc, wc = win - wr * g.nwc;
 
+  #ifdef ATT_WAVE_SCALAR
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#endif
   const int l31 = lane & 31, h = lane >> 5;
   const int hoff = head * HD;
   // halves offset of this head's q / k / v slice inside a split row (64 d = 2 chunks = 128 halves)
   const long qoff = 2L * hoff, koff = 2L * (C + hoff), voff = 2L * (2 * C + hoff);
 
-  const int tq = (tile0 + wave) * 32 + l31;
-  const int q_tok = (tq < L && wave < n_active) ? token_of(g, wr, wc, tq) : -1;
+  const int tq = (qt * NW + wave) * 32 + l31;
+  const int q_tok = (tq < L) ? token_of(g, wr, wc, tq) : -1;
   if (!GLOBAL) {
     const long long pad_delta = reinterpret_cast<const char *>(pad_row) - reinterpret_cast<const char *>(qkv);
     for (int t = tid; t < L; t += NT) {
+#ifdef ATT_TAB_TRIVIAL   /* timing experiment: no div / mod in the table build (wrong rows) */
+      tab[t] = (long long)t * ldq * 2 + (pad_delta & 0);
+#else
       const int tok = token_of(g, wr, wc, t);
       tab[t] = (tok >= 0) ? (long long)tok * ldq * 2 : pad_delta;
+#endif
     }
   }
   const bool wave_active = __any(q_tok >= 0);
-  constexpr bool IDLE_SKIP = !GLOBAL || BAL;
+#ifdef ATT_NO_IDLE_SKIP
+  constexpr bool IDLE_SKIP = false;
+#else
+  constexpr bool IDLE_SKIP = !GLOBAL;
+#endif
   if (!__syncthreads_or(wave_active ? 1 : 0)) return;
 
   // ---- Q fragments: B operand of S^T = K.Q^T; step s covers d = 16s + 8h + (0..7) ---------
@@ -187,7 +160,10 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int n_tiles = j1 - j0;   // key tiles of this work-group (all L / 32 of them but for the key-split leftover pass)
+#ifdef ATT_PRIO_STATIC   /* experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): the later-dispatched waves */
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(ATT_PRIO_STATIC);
+#endif
+  const int n_tiles = L / 32;
   uint4 sk0 = make_uint4(0u, 0u, 0u, 0u), sk1 = sk0, sv0 = sk0, sv1 = sk0;
   // K: 16 lanes cover one 256-byte row (coalesced).  V: 32 lanes cover 32 keys at the same
   // 16-byte column, so that the transposed b16 LDS writes of a half-wave land in 32 consecutive
@@ -201,10 +177,10 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   const long vcol = voff + (tid & 15) * 8;
   // whole-grid launches walk three running row pointers (+32 rows per tile); windowed ones look
   // the rows up in the table.
-  const unsigned short *kq0 = qkv + (size_t)(krow0 + 32 * j0) * ldq + kcol;
-  const unsigned short *kq1 = qkv + (size_t)(krow1 + 32 * j0) * ldq + kcol;
-  const unsigned short *vq0 = qkv + (size_t)(krow0 + 32 * j0) * ldq + vcol;
-  const unsigned short *vq1 = qkv + (size_t)(krow1 + 32 * j0) * ldq + vcol;
+  const unsigned short *kq0 = qkv + (size_t)krow0 * ldq + kcol;
+  const unsigned short *kq1 = qkv + (size_t)krow1 * ldq + kcol;
+  const unsigned short *vq0 = qkv + (size_t)krow0 * ldq + vcol;
+  const unsigned short *vq1 = qkv + (size_t)krow1 * ldq + vcol;
   const long tile_step = 32 * ldq;
 #define CRA5_ROW(JJ, ROW) \
   reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(qkv) + tab[(JJ)*32 + (ROW)])
@@ -261,22 +237,29 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     }                                                                                     \
   }
 #define CRA5_V_STORE(BUF) { CRA5_V_STORE1(0, BUF) if (TWO) CRA5_V_STORE1(1, BUF) }
-  // S^T tile (32 keys x 32 queries) of the K buffer KB: 12 MFMAs on one accumulator (a dependent 32x32x16 MFMA
-  // issues back-to-back at full rate: tools/probes/mfma_peak.hip; 2 / 3 independent chains measured the same)
+  // S^T tile (32 keys x 32 queries) of the K buffer KB: 12 MFMAs on ATT_S_CHAINS independent
+  // accumulators (a dependent 32x32x16 MFMA cannot issue back-to-back), summed at the end.
+#ifndef ATT_S_CHAINS
+#define ATT_S_CHAINS 1
+#endif
+#define ATT_KFRAG(PTR, ALT) (*reinterpret_cast<const half8 *>(PTR))
 #define CRA5_SCORES(DST, KB)                                                              \
   {                                                                                       \
-    f32x16 acc_;                                                                          \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[r] = 0.f;                         \
+    f32x16 acc_[ATT_S_CHAINS];                                                            \
+    _Pragma("unroll") for (int c = 0; c < ATT_S_CHAINS; ++c)                              \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[c][r] = 0.f;                    \
     _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                    \
-      const half8 kh = *reinterpret_cast<const half8 *>(k_base + (KB)*KBUF + 16 * st);    \
-      const half8 kl = *reinterpret_cast<const half8 *>(k_base + (KB)*KBUF + KPL + 16 * st); \
+      const half8 kh = ATT_KFRAG(k_base + (KB)*KBUF + 16 * st, qh[3 - st]);               \
+      const half8 kl = ATT_KFRAG(k_base + (KB)*KBUF + KPL + 16 * st, ql[3 - st]);         \
       if (!HI) {                                                                          \
-        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], acc_, 0, 0, 0);         \
-        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], acc_, 0, 0, 0);         \
+        acc_[(3 * st) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], acc_[(3 * st) % ATT_S_CHAINS], 0, 0, 0); \
+        acc_[(3 * st + 1) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], acc_[(3 * st + 1) % ATT_S_CHAINS], 0, 0, 0); \
       }                                                                                   \
-      acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], acc_, 0, 0, 0);           \
+      acc_[(3 * st + 2) % ATT_S_CHAINS] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], acc_[(3 * st + 2) % ATT_S_CHAINS], 0, 0, 0); \
     }                                                                                     \
-    DST = acc_;                                                                           \
+    _Pragma("unroll") for (int c = 1; c < ATT_S_CHAINS; ++c)                              \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[0][r] += acc_[c][r];            \
+    DST = acc_[0];                                                                        \
   }
 
   const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
@@ -296,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a_), "+v"(b_));              \
     fmaxf(a_, b_);                                                                        \
   })
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(ATT_PLAIN_SPLIT) || defined(ATT_NO_MAX3) || !defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_TILE_MAX(S)                                                                  \
   ({                                                                                      \
     float m_ = fmaxf(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])), fmaxf(fmaxf(S[4], S[5]), fmaxf(S[6], S[7]))); \
@@ -358,10 +341,17 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     }
     // ---- tile j+1's 12 score MFMAs, interleaved with tile j's softmax VALU work
     // (past the last tile the scores of a stale K buffer are computed and discarded.)
+#ifdef ATT_PRIO_SOFTMAX   /* experiment: this wave's softmax VALU (and its S MFMAs) outrank the other waves' streams */
+    __builtin_amdgcn_s_setprio(ATT_PRIO_SOFTMAX);
+#endif
+#ifdef ATT_SKIP_S
+    s_next = s_cur;
+#else
     CRA5_SCORES(s_next, kb);
+#endif
     float psum = 0.f;
     half8 ph[2], pl[2];
-#if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(ATT_PLAIN_SPLIT) && !defined(ATT_SKIP_SOFTMAX) && defined(__HIP_DEVICE_COMPILE__)
     // p -> (hi, lo) with lo = p - f32(hi) as ONE v_fma_mix_f32 that reads the f16 half in place (no
     // v_cvt_f32_f16 + v_sub per element): 4 VALU per two scores instead of 7.  MFMA and VALU of the waves of a
     // SIMD do not overlap on this chip: every VALU removed here is wall time.  Only the
@@ -393,19 +383,32 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
         pl[r >> 3][(r & 7) + 1] = (_Float16)d1;
       }
     }
-#else   /* host pass: the same arithmetic without the inline asm (never executed) */
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+#if defined(ATT_SKIP_SOFTMAX)
+      const float p = s_cur[r];
+      ph[r >> 3][r & 7] = __builtin_bit_cast(_Float16, (unsigned short)__builtin_bit_cast(unsigned, p));
+      pl[r >> 3][r & 7] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned, p) >> 16));
+      psum += p;
+#else
       const float p = __builtin_amdgcn_exp2f(fmaf(s_cur[r], cexp, -m_new));
       psum += p;
       const _Float16 hi = (_Float16)p;
       const _Float16 lo = (_Float16)(p - (float)hi);
       ph[r >> 3][r & 7] = hi;
       pl[r >> 3][r & 7] = lo;
+#endif
     }
 #endif
     l_run += psum;
+#ifdef ATT_PRIO_SOFTMAX
+    __builtin_amdgcn_s_setprio(ATT_PRIO_PV);
+#endif
     // ---- O^T += V^T . P^T, with the staging traffic and tile j+1's max in its shadow
+#ifdef ATT_SKIP_PV
+    o[0][0] += (float)ph[0][0] + (float)pl[1][7] + (float)ph[1][3] + (float)pl[0][5];
+#else
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       half8 vh[2], vl[2];
@@ -428,19 +431,36 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], ph[t], o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], ph[t], o[1], 0, 0, 0);
     }
+#endif
     mloc = CRA5_TILE_MAX(s_next);
     }
+#ifdef ATT_SGB
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 K-fragment ds_reads first
+#pragma unroll
+    for (int i = 0; i < (HI ? 4 : 12); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one score MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, ATT_VALU_PER_MFMA, 0);  // softmax VALU in its shadow
+    }
+#endif
     // K(j+2) -> the buffer tile j's scores came from (last read before the previous barrier),
     // V(j+1) -> the other V buffer (past the end: stale data into buffers nobody reads);
     // then start fetching K(j+3), V(j+2).
+#ifndef ATT_SKIP_STAGE
     CRA5_K_STORE(j & 1);
     CRA5_V_STORE((j + 1) & 1);
     CRA5_K_LOAD(j + 3);
     CRA5_V_LOAD(j + 2);
+#endif
+#ifndef ATT_SKIP_BARRIER
     __syncthreads();
+#endif
   };
   f32x16 s_alt;
+#ifdef ATT_NOLOOP   /* timing experiment: prologue + epilogue only */
+  const int n_loop = 0;
+#else
   const int n_loop = n_tiles;
+#endif
   int jt = 0;
   for (; jt + 1 < n_loop; jt += 2) {
     key_tile(jt, s_cur, s_alt);
@@ -449,24 +469,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   if (jt < n_loop) key_tile(jt, s_cur, s_alt);
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (BAL && bal.mode == 1) {
-    // un-normalised partial of this key range: O, running max (log2 domain), sum - merged by attention_merge_kernel
-    if (q_tok >= 0) {
-      float *wrow = bal.ws + ((((size_t)head * bal.rem + (tile0 - bal.rem_tile0) + wave) * bal.groups + bal_c) * 32 + l31) * WS_ROW;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int d = 32 * t + 8 * gq + 4 * h;
-          *reinterpret_cast<float4 *>(wrow + d) = make_float4(o[t][4 * gq + 0], o[t][4 * gq + 1], o[t][4 * gq + 2], o[t][4 * gq + 3]);
-        }
-      if (h == 0) {
-        wrow[64] = m_run;
-        wrow[65] = l_tot;
-      }
-    }
-    return;
-  }
   if (q_tok >= 0) {
     const float inv = 1.0f / l_tot;
     float *orow = out ? out + (size_t)q_tok * C + hoff : nullptr;
@@ -487,105 +489,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   }
 }
 
-// Merge of the key-split partials of the leftover queries: block = (head, leftover tile), 256 threads = 32 queries x
-// 8 d-groups of 8; split c contributes exp2(m_c - M) (O_c, l_c), summed in split order (fixed association).
-__global__ __launch_bounds__(256) void attention_merge_kernel(const float *__restrict__ ws, float *__restrict__ out,
-                                                              unsigned short *__restrict__ out_s, int Kp_out, int C,
-                                                              int rem, int groups, int rem_tile0) {
-  const int head = blockIdx.x / rem, i = blockIdx.x - head * rem;
-  const int q = threadIdx.x >> 3, d0 = (threadIdx.x & 7) * 8;
-  const float *base = ws + (((size_t)head * rem + i) * groups * 32 + q) * WS_ROW;
-  float M = -INFINITY;
-  for (int c = 0; c < groups; ++c) M = fmaxf(M, base[(size_t)c * 32 * WS_ROW + 64]);
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lsum = 0.f;
-  for (int c = 0; c < groups; ++c) {
-    const float *r = base + (size_t)c * 32 * WS_ROW;
-    const float a = __builtin_amdgcn_exp2f(r[64] - M);
-    lsum = fmaf(r[65], a, lsum);
-    const float4 v0 = *reinterpret_cast<const float4 *>(r + d0), v1 = *reinterpret_cast<const float4 *>(r + d0 + 4);
-    acc[0] = fmaf(v0.x, a, acc[0]);
-    acc[1] = fmaf(v0.y, a, acc[1]);
-    acc[2] = fmaf(v0.z, a, acc[2]);
-    acc[3] = fmaf(v0.w, a, acc[3]);
-    acc[4] = fmaf(v1.x, a, acc[4]);
-    acc[5] = fmaf(v1.y, a, acc[5]);
-    acc[6] = fmaf(v1.z, a, acc[6]);
-    acc[7] = fmaf(v1.w, a, acc[7]);
-  }
-  const float inv = 1.0f / lsum;
-  const int tok = (rem_tile0 + i) * 32 + q, col = head * HD + d0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] *= inv;
-  if (out) {
-    *reinterpret_cast<float4 *>(out + (size_t)tok * C + col) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4 *>(out + (size_t)tok * C + col + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-  }
-  if (out_s) {
-    unsigned short *srow = out_s + (size_t)tok * 2 * Kp_out;
-    cra5_store_split4(srow, col, acc[0], acc[1], acc[2], acc[3]);
-    cra5_store_split4(srow, col + 4, acc[4], acc[5], acc[6], acc[7]);
-  }
-}
-
-int cu_count() {
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-    return v;
-  }();
-  return n;
-}
-
-constexpr int NW_GLOBAL = 12;   // 384 queries share each K/V tile (4 / 8 / 12 waves per work-group: 1.59 / 1.56 / 1.52 ms)
-constexpr int NW_REM = 4;       // leftover pass: one wave per SIMD
-
-// geometry of the balanced schedule for L tokens, `heads` heads on this device; false = use the plain launch
-bool balanced_plan(int L, int heads, BalArgs &b) {
-  const int P = cu_count(), T = L / 32;
-  if (P % heads) return false;
-  b.groups = P / heads;
-  b.base = T / b.groups;
-  b.rem = T - b.base * b.groups;
-  b.rem_tile0 = b.groups * b.base;
-  b.n_wg_pass = heads * b.groups;
-  b.mode = 0;
-  b.ws = nullptr;
-  // worth it only when a slot has at least one full pass of wave-tiles, and the key split leaves every range a tile
-  return b.base >= NW_GLOBAL && T >= b.groups;
-}
-
-size_t balanced_ws_bytes(const BalArgs &b, int heads) {
-  return (size_t)heads * b.rem * b.groups * 32 * WS_ROW * sizeof(float);
-}
-
-template <bool HI>
-int launch_balanced(const unsigned short *qkv, long ldq, const unsigned short *pad_row, float *out, unsigned short *out_s,
-                    int Kp_out, int C, int heads, int H, int W, float scale, BalArgs b, float *ws, hipStream_t st) {
-  WinGeom g;
-  g.H = H;
-  g.W = W;
-  g.wh = H;
-  g.ww = W;
-  g.nwc = 1;
-  const int n_pass = (b.base + NW_GLOBAL - 1) / NW_GLOBAL;
-  hipLaunchKernelGGL((window_attention_split_kernel<NW_GLOBAL, HI, true, true>), dim3(n_pass * b.n_wg_pass),
-                     dim3(NW_GLOBAL * 64), 0, st, qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, 0, scale, b);
-  int rc = (int)hipGetLastError();
-  if (rc || b.rem == 0) return rc;
-  BalArgs r = b;
-  r.mode = 1;
-  r.ws = ws;
-  const int n_chunk = (b.rem + NW_REM - 1) / NW_REM;
-  hipLaunchKernelGGL((window_attention_split_kernel<NW_REM, HI, true, true>), dim3(n_chunk * b.n_wg_pass),
-                     dim3(NW_REM * 64), 0, st, qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, 0, scale, r);
-  rc = (int)hipGetLastError();
-  if (rc) return rc;
-  hipLaunchKernelGGL(attention_merge_kernel, dim3(heads * b.rem), dim3(256), 0, st, ws, out, out_s, Kp_out, C, b.rem,
-                     b.groups, b.rem_tile0);
-  return (int)hipGetLastError();
-}
-
 template <int NW, bool HI, bool GLOBAL>
 int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, float *out, unsigned short *out_s,
            int Kp_out, int C, int heads, int H, int W, int wh, int ww, float scale, hipStream_t st) {
@@ -599,15 +502,15 @@ int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, f
   const int L = wh * ww;
   const int q_tiles = (L + NW * 32 - 1) / (NW * 32);
   hipLaunchKernelGGL((window_attention_split_kernel<NW, HI, GLOBAL>), dim3(q_tiles * nwr * g.nwc * heads), dim3(NW * 64), 0, st,
-                     qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, q_tiles, scale, BalArgs{});
+                     qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, q_tiles, scale);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split, float *out,
-                              uint16_t *out_split, int out_kp, int C, int heads, int H, int W, int wh, int ww,
-                              float scale, int hi_only, void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
+                                           float *out, uint16_t *out_split, int out_kp, int C, int heads, int H,
+                                           int W, int wh, int ww, float scale, int hi_only, void *stream) {
   if (!qkv_split || !pad_row_split || (!out && !out_split) || heads <= 0 || C % heads) return CRA5_ERR_ARG;
   if (C / heads != 64 || qkv_kp != 3 * C) return CRA5_ERR_ARG;  // head slices must be chunk-aligned
   if (wh <= 0 || ww <= 0 || H <= 0 || W <= 0 || (wh * ww) % 32) return CRA5_ERR_ARG;
@@ -620,44 +523,26 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   if (!whole && L > MAX_WIN_TOKENS) return CRA5_ERR_ARG;   // attention_f32.hip covers those
 #define CRA5_ATT_GO(NWV, HIV, GLV) \
   return launch<NWV, HIV, GLV>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st)
+#ifndef ATT_NW_GLOBAL
+#define ATT_NW_GLOBAL 12   /* 384 queries share each K/V tile (4 / 8 / 12 waves: 1.59 / 1.56 / 1.52 ms) */
+#endif
   if (whole) {
-    BalArgs b;
-    if (workspace && ((uintptr_t)workspace & 15) == 0 && balanced_plan(L, heads, b) &&
-        workspace_bytes >= balanced_ws_bytes(b, heads)) {
-      float *ws = reinterpret_cast<float *>(workspace);
-      if (hi_only)
-        return launch_balanced<true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, scale, b, ws, st);
-      return launch_balanced<false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, scale, b, ws, st);
-    }
-    if (hi_only) CRA5_ATT_GO(NW_GLOBAL, true, true);
-    CRA5_ATT_GO(NW_GLOBAL, false, true);
+    if (hi_only) CRA5_ATT_GO(ATT_NW_GLOBAL, true, true);
+    CRA5_ATT_GO(ATT_NW_GLOBAL, false, true);
   }
   // Windows: 4-wave work-groups (128 queries), three per CU.  The 6-wave form (192 queries: 3 exact blocks per 576-token
   // window, K / V staged three times instead of five) looks better on paper and ran with ONE work-group per CU: its
   // waves land on the SIMDs 2-2-1-1, a second work-group would put four 156-register waves on one SIMD (3 fit), so
   // 864 work-groups took 3.4 rounds instead of 1.7.  Four waves are one per SIMD: three work-groups always fit.
+  // (-DATT_NW_WINDOW=6 selects the 6-wave form.)
+#ifndef ATT_NW_WINDOW
+#define ATT_NW_WINDOW 4
+#endif
+  if (ATT_NW_WINDOW == 6 && L % 192 == 0 && L <= 1152) {
+    if (hi_only) CRA5_ATT_GO(6, true, false);
+    CRA5_ATT_GO(6, false, false);
+  }
   if (hi_only) CRA5_ATT_GO(4, true, false);
   CRA5_ATT_GO(4, false, false);
 #undef CRA5_ATT_GO
-}
-
-extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
-                                           float *out, uint16_t *out_split, int out_kp, int C, int heads, int H,
-                                           int W, int wh, int ww, float scale, int hi_only, void *stream) {
-  return attention_dispatch(qkv_split, qkv_kp, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale,
-                            hi_only, nullptr, 0, stream);
-}
-
-extern "C" size_t cra5_attention_workspace_bytes(int n_tokens, int heads) {
-  BalArgs b;
-  if (n_tokens <= 0 || heads <= 0 || (n_tokens % 32) || !balanced_plan(n_tokens, heads, b)) return 0;
-  return balanced_ws_bytes(b, heads);
-}
-
-extern "C" int cra5_window_attention_split_ws(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
-                                              float *out, uint16_t *out_split, int out_kp, int C, int heads, int H,
-                                              int W, int wh, int ww, float scale, int hi_only, void *workspace,
-                                              size_t workspace_bytes, void *stream) {
-  return attention_dispatch(qkv_split, qkv_kp, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale,
-                            hi_only, workspace, workspace_bytes, stream);
 }
