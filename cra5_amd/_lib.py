@@ -40,10 +40,6 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_void_p]),
     "cra5_gemm_nt_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "cra5_gemm_sk_workspace_bytes": (c_size_t, []),
-    "cra5_gemm_nt_split_sk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                                      c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t,
-                                      c_void_p]),
     "cra5_split_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "cra5_layernorm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_float, c_void_p]),

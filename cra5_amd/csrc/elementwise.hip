@@ -152,17 +152,11 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ c
 // writes 8*kh*kw consecutive K entries (3.5 KB runs).  HBM-bound: 1.11 GB in, 1.22 GB out.
 // ---------------------------------------------------------------------------------------
 constexpr int TILE_TOK = 16;
-#ifndef CRA5_I2C_TILE_CH
-#define CRA5_I2C_TILE_CH 2
-#endif
-#ifndef CRA5_C2I_TILE_CH
-#define CRA5_C2I_TILE_CH 2
-#endif
 // channels per block: 8 -> 2 took the gather from 44 % to 54 % and the scatter from 31 % to 63 % of the
 // HBM peak (LDS per block 56 KB -> 14 KB: 2 -> 8 resident blocks per CU; tools/mem_bench.py).  Must stay
 // even: the K offset c0*KH*KW of a block has to be a multiple of 4 floats for the 16-byte accesses.
-constexpr int TILE_CH = CRA5_I2C_TILE_CH;      // gather (im2col)
-constexpr int TILE_CH_S = CRA5_C2I_TILE_CH;    // scatter (col2im)
+constexpr int TILE_CH = 2;      // gather (im2col)
+constexpr int TILE_CH_S = 2;    // scatter (col2im)
 
 // LDS image of both kernels: token-major [16 tokens][8*KH*KW (+4 pad)] = the GEMM-side layout,
 // so the GEMM-side accesses are contiguous ds_read/write_b128 + 16-byte global accesses, and the

@@ -111,19 +111,11 @@ __device__ unsigned long long g_gemm_trace[5 * 8192];
 #define CRA5_TRACE(slot)
 #endif
 
-// Stream-K work split of the persistent variant (SK = true): `dp_rounds` full rounds of one tile per
-// work-group, then the remaining `sk_tiles` tiles cut along K into P equal iteration ranges.
-struct SkArgs {
-  float *ws;            // [2 P] partial accumulator tiles of BM x BN floats (MFMA register layout)
-  unsigned *counters;   // [sk_tiles] arrivals per split tile, zero between launches (the last arriver resets)
-  int dp_rounds, sk_tiles;
-};
-
-template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3, bool SK = false>
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3>
 __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM == 3)) ? 2 : 1)) void gemm_nt_split_kernel(
     const unsigned short *__restrict__ A, long lda, const unsigned short *__restrict__ W, long ldw, float *C,
     int ldc, unsigned short *Cs, long ldcs, const float *__restrict__ bias, const float *res, int ldr, int M,
-    int N, int Kp, float wscale_inv, int flags, int tiles_n, SkArgs sk) {
+    int N, int Kp, float wscale_inv, int flags, int tiles_n) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int NT = WM * WN * 64;
@@ -135,12 +127,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
 
   // two stages of [A rows][W rows], 128 B per row = [32 hi | 32 lo] of one k-step, XOR-swizzled in
   // 16-byte pieces (see the staging comment below); 2 x (BM + BN) x 128 B, no padding.
-#if defined(GEMM_PF)
-  constexpr int PF_SINK = (TM >= 3 && NPROD == 3 && WM == 2 && WN == 4 && !LONGK) ? WM * WN * 128 : 0;   // halves
-#else
-  constexpr int PF_SINK = 0;
-#endif
-  __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE + PF_SINK];
+  __shared__ __attribute__((aligned(16))) unsigned short lds[STAGES * STAGE];
 
   CRA5_TRACE(0);
 #ifdef CRA5_GEMM_TRACE
@@ -148,81 +135,20 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
 #endif
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int tid = threadIdx.x;
-  // the wave index as a SCALAR for the 256 x 256 tiles: everything derived from it - the LDS-DMA destinations
-  // above all - stays in SGPRs (m0 = s_add instead of v_add_u32 + v_readfirstlane_b32 + s_mov per 1-KB DMA
-  // instruction; 42 -> 28 instructions per k-step of staging).  Measured, interleaved A/B: qkv 184 -> 175 us,
-  // fc1 279 -> 270, un-embed 1776 -> 1670; the 192 x 256 instantiation got 2-3 % SLOWER with it (fc2 233 -> 241)
-  // and keeps the vector form.  (A uniform byte cursor + 32-bit lane offsets did NOT make hipcc pick the
-  // saddr + voffset encoding for __builtin_amdgcn_global_load_lds: it rebuilt a 64-bit address per instruction.)
-#ifndef GEMM_SCALAR_ALL
-#define GEMM_SCALAR_ALL 0
-#endif
-// Hand-written LDS-DMA (saddr + voffset encoding, no address VALU in the k-loop): on by default for the 256 x 256
-// and the 192 x 256 instantiations; -DGEMM_NO_ASM_DMA builds the __builtin_amdgcn_global_load_lds form everywhere.
-#if !defined(GEMM_NO_ASM_DMA) && !defined(GEMM_ASM_DMA)
-#define GEMM_ASM_DMA
-#endif
-#ifndef GEMM_ASM_DMA_192
-#define GEMM_ASM_DMA_192 1
-#endif
-#ifdef GEMM_WAVE_VGPR   /* A/B: the round-1 form everywhere */
-  const int lane = tid & 63, wave = tid >> 6;
+  // the wave index as a SCALAR: everything derived from it - the LDS-DMA destinations above all - stays in SGPRs
+  // (m0 = s_add instead of v_add_u32 + v_readfirstlane_b32 + s_mov per 1-KB DMA instruction; 42 -> 28 instructions per
+  // k-step of staging.  Measured, interleaved A/B: qkv 184 -> 175 us, fc1 279 -> 270, un-embed 1776 -> 1670)
+  const int lane = tid & 63, wave = (NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int wave_dma = wave;
-#elif defined(GEMM_WAVE_DMA_ONLY)   /* A/B: scalar only where the LDS-DMA destination is formed */
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wave_dma = __builtin_amdgcn_readfirstlane(tid >> 6);
-#else
-  const int lane = tid & 63, wave = ((TM == 4 || GEMM_SCALAR_ALL || GEMM_ASM_DMA_192) && NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
-  const int wave_dma = wave;
-#endif
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int nk_all = Kp / BK;
 
-  // ---- persistent stream-K schedule (SK): this work-group's items ---------------------------------
-  // Iterations of the sk tiles are numbered tile-major (tile t: [t nk, (t+1) nk)); work-group v owns
-  // [v I / P, (v+1) I / P), at most two tile segments because I / P < nk: `hi` (the beginning of the
-  // later tile) runs FIRST, then the data-parallel tiles, `lo` (the end of the earlier tile) LAST.
-  // A segment that is not a whole tile parks its accumulators in the workspace; the last of a tile's
-  // contributors to arrive (atomic counter) adds them up in k order - a fixed order - and runs the
-  // epilogue.  Nobody ever waits for another work-group: concurrent kernels cannot deadlock.
-  __shared__ int sk_last;
-  const int P = gridDim.x;
-  long sk_s = 0, sk_e = 0, sk_total = 0;
-  int n_items = 1, n_hi = 0;
-  if (SK) {
-    sk_total = (long)sk.sk_tiles * nk_all;
-    sk_s = (long)pid * sk_total / P;
-    sk_e = (long)(pid + 1) * sk_total / P;
-    const bool two = sk_e > sk_s && (sk_s / nk_all) != ((sk_e - 1) / nk_all);
-    n_hi = two ? 1 : 0;
-    n_items = n_hi + sk.dp_rounds + ((sk_e > sk_s) ? 1 : 0);
-  }
-  for (int item = 0; item < n_items; ++item) {
-  int tile = pid, ka = 0, kb = nk_all, my_slot = 0;
-  if (SK) {
-    if (item < n_hi) {                                   // hi segment: [tile_hi * nk, sk_e)
-      const int t = (int)((sk_e - 1) / nk_all);
-      tile = sk.dp_rounds * P + t;
-      ka = 0;
-      kb = (int)(sk_e - (long)t * nk_all);
-      my_slot = 2 * pid + 1;
-    } else if (item < n_hi + sk.dp_rounds) {
-      tile = (item - n_hi) * P + pid;
-    } else {                                             // lo segment: [sk_s, min(sk_e, end of its tile))
-      const int t = (int)(sk_s / nk_all);
-      tile = sk.dp_rounds * P + t;
-      ka = (int)(sk_s - (long)t * nk_all);
-      kb = (int)(((sk_e < (long)(t + 1) * nk_all) ? sk_e : (long)(t + 1) * nk_all) - (long)t * nk_all);
-      my_slot = 2 * pid;
-    }
-  }
+  const int tile = pid, ka = 0, kb = nk_all;
   // Tile order: the 32 work-groups an XCD runs at a time own 32 CONSECUTIVE tile numbers (xcd_remap), so tiles are
   // numbered in bands of GEMM_GROUP_M tile rows, column-major inside a band: 32 consecutive tiles = 4 A panels x 8 W
   // panels through that XCD's L2 per round (12 panel reads) instead of 2 x 16 (18) in row-major order.
-#ifndef GEMM_GROUP_M
-#define GEMM_GROUP_M 4
-#endif
+  constexpr int GEMM_GROUP_M = 4;
   int tm, tn;
   if (GEMM_GROUP_M > 1) {
     const int tiles_m = (M + BM - 1) / BM;
@@ -250,7 +176,6 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   constexpr int IPW = (GROUPS + NWAVE - 1) / NWAVE;              // LDS-DMA instructions per wave per k-step
   static_assert(NPROD == 1 || GROUPS % NWAVE == 0, "groups must divide evenly over the waves");
   const unsigned short *src[IPW];
-#ifdef GEMM_ASM_DMA
   // Hand-written LDS-DMA with the saddr + voffset encoding: a uniform 64-bit cursor per operand (advanced by an
   // s_add per k-step) + a fixed 32-bit byte offset per lane and instruction - no address VALU in the k-loop (the
   // builtin form spends a v_lshl_add_u64 per instruction per k-step, and hipcc does not pick this encoding for it).
@@ -259,13 +184,10 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // CRA5_K_BARRIER wait with an explicit s_waitcnt vmcnt(0) (exactly the DMA of the tile the barrier publishes is
   // outstanding there).  The per-lane offsets are relative to the tile's first row (< 256 rows x the row pitch: the
   // launcher refuses pitches of 2^21 k-columns (2^22 halves) and more, far above anything the path has).
-  constexpr bool ASM_DMA = ((TM == 4 || (GEMM_ASM_DMA_192 && TM == 3)) && NPROD == 3 && WM == 2 && (WN == 4 || (WN == 2 && TM == 3)) && !LONGK);
+  constexpr bool ASM_DMA = ((TM == 4 || TM == 3) && NPROD == 3 && WM == 2 && WN == 4 && !LONGK);
   static_assert(!ASM_DMA || BM % (WM * WN * 8) == 0, "A / W staging instructions must not straddle");
   unsigned soff[IPW];
   unsigned long long curA = 0, curW = 0;
-#else
-  constexpr bool ASM_DMA = false;
-#endif
   // NPROD == 3: one instruction = 8 rows x 128 B: a row's [32 hi | 32 lo] chunk is one cache line, requested
   // once (16 rows x 64 B of one plane per instruction asked for every line twice: -3..6 % on the 192x256
   // tiles).  LDS rows are 128 B = 8 pieces [hi 0-3 | lo 4-7]; piece p of row r lives at physical piece
@@ -285,69 +207,22 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
         src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + lpiece * 8 + (size_t)ka * 64;
       else
         src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + lpiece * 8 + (size_t)ka * 64;
-#ifdef GEMM_ASM_DMA
       if (ASM_DMA)
         soff[q] = (unsigned)((((size_t)(isA ? (size_t)(min(m0 + row_, M - 1) - m0) * lda : (size_t)(min(n0 + row_, N - 1) - n0) * ldw)) + lpiece * 8) * 2);
-#endif
     }
   }
-#ifdef GEMM_ASM_DMA
   if (ASM_DMA) {
     curA = reinterpret_cast<unsigned long long>(A + (size_t)m0 * lda) + (unsigned long long)ka * 128;
     curW = reinterpret_cast<unsigned long long>(W + (size_t)n0 * ldw) + (unsigned long long)ka * 128;
   }
-#endif
-  // L2 prefetch (GEMM_PF): the work-groups that share an operand panel run in lock-step, so the LDS-DMA of a k-slice
-  // is the FIRST touch of its lines for a whole XCD - every DMA pays the fabric latency (Infinity Cache / HBM), not the
-  // L2 hit latency, and two 64-KB stages only cover one k-step of it (elimination run: without the DMA the kernel is
-  // 15-25 % faster).  One dword load per wave and k-step - lane l touches the line of row (l & 7) of this wave's DMA
-  // instruction (l >> 3), PF_DIST k-steps beyond the tile being staged - pulls those lines into L2 ahead of time.
-  // Nobody waits for it: it is issued right after a stage's DMA instructions and the barrier waits with vmcnt(1).
-#if defined(GEMM_PF) && defined(GEMM_ASM_DMA)
-  constexpr bool PF = ASM_DMA;
-#else
-  constexpr bool PF = false;
-#endif
-#ifndef GEMM_PF_DIST
-#define GEMM_PF_DIST 2
-#endif
-  const unsigned short *pf_ptr = A;
-  int pf_tile = 0;
-  const unsigned pf_sink_lds = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned short *)(lds + STAGES * STAGE)) + wave_dma * 256;
-  if (PF) {
-    const int q = min(lane >> 3, IPW - 1), grow = (wave + q * NWAVE) * 8;
-    const bool isA = grow < BM;
-    const int row_ = (isA ? grow : grow - BM) + (lane & 7);
-    pf_tile = min(1 + GEMM_PF_DIST, kb - ka - 1);
-    pf_ptr = (isA ? A + (size_t)min(m0 + row_, M - 1) * lda : W + (size_t)min(n0 + row_, N - 1) * ldw) +
-             (size_t)(ka + pf_tile) * 64;
-  }
-#if defined(__HIP_DEVICE_COMPILE__)
-#define CRA5_PF_ISSUE                                                                          \
-  if (PF) {                                                                                    \
-    /* the sink is a 256-byte LDS slot per wave behind the stages: a VGPR destination would be clobbered when the   \
-       load returns, long after hipcc has given the register to something else */                                   \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"                \
-                 :: "s"(pf_sink_lds), "v"(pf_ptr) : "memory", "m0");                           \
-    const bool more_ = pf_tile + 1 < kb - ka;                                                  \
-    pf_tile += more_ ? 1 : 0;                                                                  \
-    pf_ptr += more_ ? 64 : 0;                                                                  \
-  }
-#else
-#define CRA5_PF_ISSUE
-#endif
   // (the builtin only exists in the device pass; the host pass just needs the launch stub)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_GLDS16(SRC, DST) __builtin_amdgcn_global_load_lds(SRC, DST, 16, 0, 0)
 #else
 #define CRA5_GLDS16(SRC, DST) (void)(SRC)
 #endif
-#ifdef GEMM_DMA_SAMEK   /* timing experiment, wrong results: every k-step stages the same (cache-resident) k-slice */
-#define CRA5_DMA_KSTRIDE 0
-#else
 #define CRA5_DMA_KSTRIDE 128
-#endif
-#if defined(GEMM_ASM_DMA) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_STAGE_LOAD(BUF)                                                                   \
   {                                                                                            \
     if (ASM_DMA) {                                                                             \
@@ -443,11 +318,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // pipe idled through barrier skew + the first ds_reads of the new stage, 20 of 78 us per tile.
   const int nk = kb - ka;
   half8 f0ah[TM], f0al[TM], f0bh[TN], f0bl[TN], f1ah[TM], f1al[TM], f1bh[TN], f1bl[TN];
-#if !defined(GEMM_NO_PINGPONG) && defined(GEMM_ASM_DMA)
   constexpr bool PP = ASM_DMA;
-#else
-  constexpr bool PP = false;
-#endif
   // Ping-pong main loop (PP; the 256 x 256 and 192 x 256 instantiations): the two waves of a SIMD (wave w and w + 4:
   // wm = 0 | 1) run the same four phases per k-step - read the fragments of a 16-wide k-half, MFMA it, read the
   // other half, MFMA it - ONE PHASE APART, a raw s_barrier at every phase boundary: while one wave of the SIMD feeds
@@ -470,17 +341,8 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     __builtin_amdgcn_sched_barrier(0);         \
     asm volatile("" ::: "memory");             \
   }
-#ifdef GEMM_PP_SKIPDMA   /* timing experiments of tools/ab_bench.sh (wrong results) */
-#define CRA5_PP_DMA_ON false
-#else
-#define CRA5_PP_DMA_ON true
-#endif
-#ifdef GEMM_PP_SKIPREAD
-#define CRA5_PP_READ(ST, KK) if (kt == 0) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, ST, KK)
-#else
 #define CRA5_PP_READ(ST, KK) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, ST, KK)
-#endif
-#define CRA5_PP_DRAIN { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#define CRA5_PP_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
   if (PP) {
     CRA5_STAGE_LOAD(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -491,7 +353,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
       const unsigned short *st = lds + (kt & 1) * STAGE;
       CRA5_PP_READ(st, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + 1 < nk && CRA5_PP_DMA_ON) { CRA5_STAGE_LOAD((kt + 1) & 1); CRA5_PF_ISSUE; }
+      if (kt + 1 < nk) CRA5_STAGE_LOAD((kt + 1) & 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       CRA5_PP_BARRIER;
       CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
@@ -507,18 +369,12 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     if (wm == 0) CRA5_PP_BARRIER;
   } else {
   CRA5_STAGE_LOAD(0);
-#ifdef GEMM_ASM_DMA
-  if (ASM_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
   __syncthreads();   // (hipcc drains vmcnt before the barrier: tile 0 has landed for everyone)
   CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds, 0);
-  if (nk > 1) { CRA5_STAGE_LOAD(1); CRA5_PF_ISSUE; }
+  if (nk > 1) CRA5_STAGE_LOAD(1);
   CRA5_TRACE(1);
 
-  // One k-step.  -DGEMM_UNROLL2 unrolls the loop by two with the stage index a literal (fragment addresses of both
-  // stages loop-invariant, no 10 v_add_u32 per step; `#pragma unroll 2` is ignored on this loop: barrier + branches):
-  // measured 1.5-3 % SLOWER on every shape (11 address registers spill in the 256 x 256 instantiation, twice the
-  // loop body in the instruction cache) - off.
+  // One k-step (an unroll by two with literal stage indexes measured 1.5-3 % slower: tools/probes/archive).
 #define CRA5_K_STEP(KT, CUR)                                                                     \
   {                                                                                              \
     CRA5_FRAG_READ(f1ah, f1al, f1bh, f1bl, lds + (CUR)*STAGE, 1);                                \
@@ -527,9 +383,8 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     if ((KT) + 1 < nk) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, lds + ((CUR) ^ 1) * STAGE, 0);     \
     /* (dealing the DMA instructions out between the MFMAs instead of issuing them here in a burst  \
        measured the same: 76-78 us per tile either way) */                                       \
-    CRA5_K_STAGE_EARLY(KT, CUR);                                                                 \
+    if ((KT) + 2 < nk) CRA5_STAGE_LOAD(CUR);                                                     \
     CRA5_MFMA_GROUP(f1ah, f1al, f1bh, f1bl);                                                     \
-    CRA5_K_STAGE_LATE(KT, CUR);                                                                  \
     if (LONGK && (((KT) & 15) == 15)) {                                                          \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                           \
@@ -539,39 +394,10 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
           }                                                                                      \
     }                                                                                            \
   }
-#if defined(GEMM_ASM_DMA)
-#define CRA5_K_BARRIER { if (ASM_DMA) { if (PF) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } __syncthreads(); }
-#elif !defined(GEMM_SKIP_BARRIER)   /* GEMM_SKIP_* : timing experiments of tools/gemm_trace.py (wrong results) */
 #define CRA5_K_BARRIER __syncthreads()
-#else
-#define CRA5_K_BARRIER
-#endif
-#ifndef GEMM_SKIP_STAGE
-#define CRA5_K_STAGE(KT, CUR) if ((KT) + 2 < nk) { CRA5_STAGE_LOAD(CUR); CRA5_PF_ISSUE; }
-#else
-#define CRA5_K_STAGE(KT, CUR)
-#endif
-#ifdef GEMM_STAGE_LATE   /* experiment: issue the LDS-DMA of tile kt+2 after the step's second MFMA group: 4-9 % slower */
-#define CRA5_K_STAGE_EARLY(KT, CUR)
-#define CRA5_K_STAGE_LATE(KT, CUR) CRA5_K_STAGE(KT, CUR)
-#else
-#define CRA5_K_STAGE_EARLY(KT, CUR) CRA5_K_STAGE(KT, CUR)
-#define CRA5_K_STAGE_LATE(KT, CUR)
-#endif
-  {
-    int kt = 0;
-#ifdef GEMM_UNROLL2
-    for (; kt + 1 < nk; kt += 2) {
-      CRA5_K_STEP(kt, 0);
-      CRA5_K_STEP(kt + 1, 1);
-    }
-    if (kt < nk) CRA5_K_STEP(kt, 0);
-#else
-    for (; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      CRA5_K_STEP(kt, cur);
-    }
-#endif
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    CRA5_K_STEP(kt, cur);
   }
   }   // !PP
   __syncthreads();   // the epilogue reuses the stages as scratch
@@ -602,50 +428,10 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     for (int c = 0; c < 4; ++c)
       if (nw + c < N) bv[c] = bias[nw + c];
   }
-  // stream-K bookkeeping of a split tile (see the schedule comment above)
-  constexpr int TILE_F = BM * BN;
-  int p_first = 0, p_last = -1;
-  long sk_t0 = 0;
-  // MODE 0: accumulators -> outputs.  MODE 1 (split tile): accumulators -> this segment's partial tile in the
-  // workspace, raw fp32 [BM][BN] (published by the agent-scope release of the arrival counter).  MODE 2 (last
-  // arriver of a split tile): sum of ALL its partial tiles in k order (our own re-read, so the association
-  // does not depend on who arrived last) -> outputs.  (gemm_split_epilogue.inc, included once per mode.)
-  if (SK && (ka != 0 || kb != nk_all)) {
-#define EPI_MODE 1
-#include "gemm_split_epilogue.inc"
-#undef EPI_MODE
-    // contributors of this tile: work-groups whose ranges meet [t nk, (t+1) nk)
-    const int t_sk = tile - sk.dp_rounds * P;
-    sk_t0 = (long)t_sk * nk_all;
-    const long t1 = sk_t0 + nk_all;
-    p_first = (int)(sk_t0 * P / sk_total);
-    p_last = (int)((t1 - 1) * P / sk_total);
-    while ((long)(p_first + 1) * sk_total / P <= sk_t0) ++p_first;
-    while ((long)p_first * sk_total / P > sk_t0) --p_first;
-    while ((long)(p_last + 1) * sk_total / P <= t1 - 1) ++p_last;
-    while ((long)p_last * sk_total / P > t1 - 1) --p_last;
-    // every wave's partial stores have reached this XCD's L2 (s_waitcnt vmcnt(0) precedes the barrier); ONE
-    // thread then releases at agent scope (L2 write-back: the other XCDs read the workspace through memory),
-    // counts the arrival, and - if it was the last - acquires before anybody reads the other partial tiles.
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned n_contrib = (unsigned)(p_last - p_first + 1);
-      const unsigned prev = __hip_atomic_fetch_add(sk.counters + t_sk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (prev + 1 == n_contrib);
-      if (last) __hip_atomic_store(sk.counters + t_sk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sk_last = last;
-    }
-    __syncthreads();
-    if (sk_last) {
-#define EPI_MODE 2
-#include "gemm_split_epilogue.inc"
-#undef EPI_MODE
-    }
-  } else {
+  {
     // interior tiles of the four epilogue shapes the model uses take the straight-line body; everything else (edge
     // tiles, unaligned outputs, both outputs at once, long-K master accumulators) the generic one
-#ifndef GEMM_NO_FAST_EPILOGUE
-    const bool interior = !LONGK && !SK && m0 + BM <= M && n0 + BN <= N;
+    const bool interior = !LONGK && m0 + BM <= M && n0 + BN <= N;
     const bool c_only = C && !Cs && vecC && !do_gelu;
     const bool s_only = Cs && !C && !has_res && ((ldcs & 3) == 0) && ((reinterpret_cast<size_t>(Cs) & 7) == 0);
     const bool bias_ok = has_bias || true;   // bv[] is zero without a bias
@@ -665,16 +451,10 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
 #define EPI_KIND 3
 #include "gemm_split_epilogue_fast.inc"
 #undef EPI_KIND
-    } else
-#endif
-    {
-#define EPI_MODE 0
+    } else {
 #include "gemm_split_epilogue.inc"
-#undef EPI_MODE
     }
   }
-  if (SK) __syncthreads();   // the next item's LDS-DMA overwrites the epilogue scratch
-  }  // item loop
   CRA5_TRACE(3);
 #ifdef CRA5_GEMM_TRACE
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_trace[blockIdx.x * 5 + 4] = clock64() - g_gemm_trace[blockIdx.x * 5 + 4];
@@ -700,37 +480,7 @@ int launch(const unsigned short *A, long lda, const unsigned short *W, long ldw,
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK, STAGES, NPROD>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
-                     st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n,
-                     SkArgs{nullptr, nullptr, 0, 0});
-  return (int)hipGetLastError();
-}
-
-constexpr int SK_BM = 256, SK_BN = 256;
-constexpr size_t SK_COUNTER_BYTES = 4096;   // >= 4 * P
-
-int cu_count() {
-  static const int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-    return v;
-  }();
-  return n;
-}
-
-// persistent hybrid stream-K launch of the 256 x 256 tile kernel: one resident work-group per CU
-int launch_sk(const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C, int ldc,
-              unsigned short *Cs, long ldcs, const float *bias, const float *res, int ldr, int M, int N, int Kp,
-              float wscale_inv, int flags, void *workspace, hipStream_t st) {
-  const int tiles_m = (M + SK_BM - 1) / SK_BM, tiles_n = (N + SK_BN - 1) / SK_BN;
-  const int T = tiles_m * tiles_n, P = cu_count();
-  SkArgs sk;
-  sk.counters = reinterpret_cast<unsigned *>(workspace);
-  sk.ws = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + SK_COUNTER_BYTES);
-  sk.dp_rounds = T / P;
-  sk.sk_tiles = T - sk.dp_rounds * P;
-  hipLaunchKernelGGL((gemm_nt_split_kernel<2, 4, 4, 2, false, 2, 3, true>), dim3(P), dim3(512), 0, st, A, lda, W, ldw,
-                     C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n, sk);
+                     st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n);
   return (int)hipGetLastError();
 }
 
@@ -769,11 +519,6 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
   // LDS fragment traffic per MFMA - compiles spill-free but measured 4-5 % SLOWER with hipcc's schedule: qkv 197 vs
   // 190 us, un-embed 1922 vs 1832; a single wave per SIMD needs a hand-placed MFMA / ds_read / LDS-DMA interleave)
   if (tile == 64) CRA5_GO(2, 2, 1, 1, false);
-#ifdef GEMM_TILE_193   /* experiment: 192 x 128 tiles on 4 waves, 80 KB of LDS = two independent work-groups per CU (one's epilogue
-                         beside the other's main loop): qkv 170 -> 198 us, un-embed 1678 -> 1765, fc1 258 -> 254 - the main loop
-                         pays more for the 1.67 x LDS-DMA traffic per MFMA than the overlap returns */
-  if (tile == 193) CRA5_GO(2, 2, 3, 2, false);
-#endif
   if (tile == 192) CRA5_GO(2, 4, 3, 2, false);   // 192 x 256, 8 waves (2 x 4), 3 x 2 sub-tiles per wave
   if (tile == 256) CRA5_GO(2, 4, 4, 2, false);   // 256 x 256, 8 waves (2 x 4), 4 x 2 sub-tiles per wave
   CRA5_GO(2, 2, 2, 2, false);
@@ -819,51 +564,6 @@ extern "C" __attribute__((visibility("hidden"))) int cra5_internal_gemm_split_ti
     int tile, hipStream_t st) {
   if (tile == 64) return launch<2, 2, 1, 1, false>(A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
   return launch<2, 2, 2, 2, false>(A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
-}
-
-extern "C" size_t cra5_gemm_sk_workspace_bytes(void) {
-  return SK_COUNTER_BYTES + (size_t)2 * cu_count() * SK_BM * SK_BN * sizeof(float);
-}
-
-extern "C" int cra5_gemm_nt_split_sk(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw_kp, float *C, int ldc,
-                                     uint16_t *C_split, int ldc_split_kp, const float *bias, const float *res, int ldr,
-                                     int M, int N, int Kp, float wscale_inv, int flags, void *workspace,
-                                     size_t workspace_bytes, void *stream) {
-  // mode: 0 = never (plain launch; DEFAULT - measured on MI355X the schedule loses),
-  // 1 = where the round-count model predicts a gain, 2 = whenever legal
-  static const int mode = [] {
-    const char *e = getenv("CRA5_GEMM_SK");
-    return e ? atoi(e) : 0;
-  }();
-  const int P = cu_count();
-  const long T = (long)((M + SK_BM - 1) / SK_BM) * ((N + SK_BN - 1) / SK_BN);
-  const int nk = Kp / BK;
-  bool legal = workspace && workspace_bytes >= cra5_gemm_sk_workspace_bytes() && ((uintptr_t)workspace & 15) == 0 &&
-               Kp > 0 && (Kp % BK) == 0 && Kp <= 8192 && !(flags & CRA5_GEMM_HI_ONLY) && M >= 1024 && N >= 1024 &&
-               (size_t)4 * P <= SK_COUNTER_BYTES;
-  const long R = T % P;
-  legal = legal && R != 0 && R * nk >= P && T >= P / 2;   // something to split, every work-group gets iterations
-  const bool forced = flags & CRA5_GEMM_SK_FORCE;
-  bool use = legal && mode != 0 && !(flags & CRA5_GEMM_SK_OFF);
-  if (forced) use = legal;
-  flags &= ~(CRA5_GEMM_SK_FORCE | CRA5_GEMM_SK_OFF);
-  if (use && mode == 1 && !forced) {
-    // plain launch: ceil(T / P) rounds (N = 1024: 192-row tiles, one round of 0.75-size tiles); stream-K:
-    // T / P rounds + ~0.12 round of fix-up traffic
-    const double plain = (N >= 2048) ? (double)((T + P - 1) / P) : 0.75 * (double)((((M + 191) / 192) * ((N + 255) / 256) + P - 1) / P);
-    use = (double)T / P + 0.12 < plain;
-  }
-  if (!use)
-    return cra5_gemm_nt_split(A, lda_kp, W, ldw_kp, C, ldc, C_split, ldc_split_kp, bias, res, ldr, M, N, Kp, wscale_inv,
-                              flags, stream);
-  if (!A || !W || (!C && !C_split) || lda_kp < Kp || ldw_kp < Kp || (lda_kp % 32) || (ldw_kp % 32)) return CRA5_ERR_ARG;
-  if (lda_kp >= (1 << 21) || ldw_kp >= (1 << 21)) return CRA5_ERR_ARG;
-  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return CRA5_ERR_ARG;
-  if ((flags & CRA5_EPI_BIAS) && !bias) return CRA5_ERR_ARG;
-  if ((flags & CRA5_EPI_RES) && !res) return CRA5_ERR_ARG;
-  if (C_split && (ldc_split_kp % 32 || ldc_split_kp < N)) return CRA5_ERR_ARG;
-  return launch_sk(A, 2L * lda_kp, W, 2L * ldw_kp, C, ldc, C_split, 2L * ldc_split_kp, bias, res, ldr, M, N, Kp,
-                   wscale_inv, flags, workspace, (hipStream_t)stream);
 }
 
 extern "C" int cra5_split_f16(const float *x, int ldx, uint16_t *out, int rows, int K, int Kp, float scale,

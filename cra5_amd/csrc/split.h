@@ -65,7 +65,7 @@ __device__ __forceinline__ void cra5_split_pair(float a, float b, unsigned &hi2,
   const float ac = cra5_sat(a), bc = cra5_sat(b);
   const half2v h2 = {(_Float16)ac, (_Float16)bc};
   hi2 = __builtin_bit_cast(unsigned, h2);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CRA5_PLAIN_SPLIT)
+#if defined(__HIP_DEVICE_COMPILE__)
   float d0, d1;
   asm("s_nop 0\n\tv_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
       "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"

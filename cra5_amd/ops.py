@@ -10,7 +10,7 @@ import torch
 
 from ._lib import check, lib
 
-EPI_BIAS, EPI_GELU, EPI_RES, GEMM_HI_ONLY, GEMM_SK_FORCE, GEMM_SK_OFF = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_RES, GEMM_HI_ONLY = 1, 2, 4, 8
 
 
 def _stream():
@@ -194,16 +194,9 @@ def split_f16(x, scale_pow2=None, out=None):
     return out
 
 
-def gemm_sk_workspace(device):
-    """A zeroed stream-K workspace (one per stream / frame thread) for gemm_nt_split(sk_ws=...)."""
-    return torch.zeros(int(lib().cra5_gemm_sk_workspace_bytes()), dtype=torch.uint8, device=device)
-
-
-def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True, hi_only=False,
-                  sk_ws=None, sk=None):
+def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True, hi_only=False):
     """epi(a @ w^T) with a, w SplitMat (same K).  out: fp32 [M, N] (row-strided ok) unless
-    want_f32=False; out_split: SplitMat [M, N] to receive the split-f16 result.  sk_ws: a
-    gemm_sk_workspace() -> the persistent stream-K schedule where it helps (csrc/gemm_split_f16.hip)."""
+    want_f32=False; out_split: SplitMat [M, N] to receive the split-f16 result."""
     _devs(a.data, w.data)
     _dev(bias, res, out)
     M, N = a.rows, w.rows
@@ -216,24 +209,13 @@ def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=Non
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
     if hi_only:
         flags |= GEMM_HI_ONLY
-    if sk is not None:   # True: force the stream-K schedule, False: force the plain launch (tests, A/B timing)
-        flags |= GEMM_SK_FORCE if sk else GEMM_SK_OFF
     ev = TIMER.start() if TIMER is not None else None
-    if sk_ws is not None:
-        check(lib().cra5_gemm_nt_split_sk(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
-                                          _row_stride(out) if out is not None else 0,
-                                          _p(out_split.data) if out_split is not None else None,
-                                          out_split.Kp if out_split is not None else 0, _p(bias), _p(res),
-                                          _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv),
-                                          flags, ctypes.c_void_p(sk_ws.data_ptr()), sk_ws.numel(), _stream()),
-              "cra5_gemm_nt_split_sk")
-    else:
-        check(lib().cra5_gemm_nt_split(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
-                                       _row_stride(out) if out is not None else 0,
-                                       _p(out_split.data) if out_split is not None else None,
-                                       out_split.Kp if out_split is not None else 0, _p(bias), _p(res),
-                                       _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv),
-                                       flags, _stream()), "cra5_gemm_nt_split")
+    check(lib().cra5_gemm_nt_split(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
+                                   _row_stride(out) if out is not None else 0,
+                                   _p(out_split.data) if out_split is not None else None,
+                                   out_split.Kp if out_split is not None else 0, _p(bias), _p(res),
+                                   _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv),
+                                   flags, _stream()), "cra5_gemm_nt_split")
     if ev is not None:
         # same rule as gemm_dispatch(): < 256 128x128 tiles -> the 64x64-tile instantiation (hyper-prior
         # and head GEMMs: microseconds, launch-bound); everything else is the 192/256-row-tile kernel

@@ -388,16 +388,6 @@ class VAEformer(nn.Module):
             ws[name] = b
         return b[1]
 
-    def _sk_workspace(self):
-        """Per-thread (= per stream) stream-K workspace of the big GEMM (csrc/gemm_split_f16.hip); only
-        when the experimental schedule is switched on (CRA5_GEMM_SK=1|2): it is off by default."""
-        if os.environ.get("CRA5_GEMM_SK", "0") in ("", "0"):
-            return None
-        ws = getattr(self._tls, "sk_ws", None)
-        if ws is None or ws.device != self.device:
-            ws = self._tls.sk_ws = ops.gemm_sk_workspace(self.device)
-        return ws
-
     def _weight2d(self, key, w):
         """GEMM-ready [N, K] view / re-layout of a parameter (cached)."""
         if key == "g_s.final":     # ConvTranspose2d (D, C, kh, kw) -> W[N = C*kh*kw][K = D]
@@ -439,13 +429,11 @@ class VAEformer(nn.Module):
         if self.gemm_mode == "split":
             W = self._wsplit(key, w)
             hi = self.precision == "f16" and key.startswith(("g_a.", "g_s."))
-            skw = self._sk_workspace()
             if out_name is not None:
                 sm = self._sbuf(out_name, a.rows, W.rows)
-                ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False, hi_only=hi,
-                                  sk_ws=skw)
+                ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False, hi_only=hi)
                 return sm
-            return ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out=out, hi_only=hi, sk_ws=skw)
+            return ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out=out, hi_only=hi)
         W = self._wf32(key, w, pad32=(a.shape[1] % 32 == 0 and self._weight2d(key, w).shape[1] != a.shape[1]))
         if out_name is not None:
             out = self._buf(out_name, (a.shape[0], W.shape[0]))

@@ -119,9 +119,6 @@ int cra5_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *
 /* cra5_gemm_nt_split only: reduced-precision mode, hi.hi product only (plain f16 operands, fp32
  * accumulate, 1 MFMA per product instead of 3) - BASELINE.json configs[4], RMSE-gated. */
 #define CRA5_GEMM_HI_ONLY 8
-/* cra5_gemm_nt_split_sk only: schedule overrides for tests / A-B timing (ignored elsewhere) */
-#define CRA5_GEMM_SK_FORCE 16   /* stream-K whenever it is legal for the shape */
-#define CRA5_GEMM_SK_OFF 32     /* plain launch */
 int cra5_gemm_nt_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc,
                      const float *bias, const float *res, int ldr, int M, int N, int K,
                      int flags, void *stream);
@@ -140,20 +137,6 @@ int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw
                        const float *res, int ldr, int M, int N, int Kp, float wscale_inv,
                        int flags, void *stream);
 
-/* The same GEMM scheduled as a PERSISTENT hybrid stream-K kernel where that balances the chip better
- * (one resident 256 x 256-tile work-group per CU: floor(T / CUs) data-parallel rounds, then the
- * remaining tiles cut along K into equal iteration ranges; split tiles are summed in k order by the
- * last contributor to arrive - deterministic, no spinning).  `workspace`: caller-owned device buffer of
- * cra5_gemm_sk_workspace_bytes() bytes, ZEROED once before its first use, private to one stream (the
- * kernel leaves its counters zero).  EXPERIMENTAL: correct and deterministic, but measured slower than
- * the plain launch on MI355X (the cross-XCD publication of the partial tiles costs more than the
- * balanced rounds save - DESIGN.md section 9), so the default is the plain launch: env CRA5_GEMM_SK =
- * 0 never (default) | 1 where a round-count model predicts a gain | 2 whenever legal. */
-size_t cra5_gemm_sk_workspace_bytes(void);
-int cra5_gemm_nt_split_sk(const uint16_t *A, int lda_kp, const uint16_t *W, int ldw_kp, float *C, int ldc,
-                          uint16_t *C_split, int ldc_split_kp, const float *bias, const float *res, int ldr,
-                          int M, int N, int Kp, float wscale_inv, int flags, void *workspace,
-                          size_t workspace_bytes, void *stream);
 
 /* fp32 [rows][K] (row stride ldx) * scale -> split-f16 [rows][2*Kp]. Used once per weight
  * tensor at load time and for the few activations no fused producer emits. */
