@@ -1,8 +1,10 @@
 #!/bin/bash
-# GPU box: MFMA-pipe utilisation per kernel (separate PMC pass, --kernel-trace only) -> gpurun_out/r02_mfma_util.json
+# GPU box: MFMA-pipe utilisation per kernel (separate PMC pass, --kernel-trace only) -> gpurun_out/ROUND/ROUND_mfma_util.json
+#   tools/pmc_mfma.sh [ROUND=r03]
+T=${1:-r03}; export CRA5_PROF_TAG=$T; mkdir -p $GRAFT_REPO_ROOT/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --exclusive --inflight 1 --no-kernel-timer > $R/gpurun_out/pmc_mfma.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-api-sample --exclusive --inflight 1 --no-kernel-timer > $R/gpurun_out/pmc_mfma.log 2>&1 < /dev/null
 cd $R
 python - <<'PY'
 import collections, csv, json
@@ -36,5 +38,7 @@ for _, k, e in sorted(rows, reverse=True)[:14]:
     out["per_kernel"][k] = e
     print(f"{k[:66]:66s} n {e['launches']:4d} mfma_util {e['mfma_util']:.3f} valu {e.get('valu_active_frac_of_wave_cycles', 0):.3f} "
           f"wait_inst {e.get('wait_inst_any_frac', 0):.3f} wait_any {e.get('wait_any_frac', 0):.3f}")
-json.dump(out, open("gpurun_out/r02_mfma_util.json", "w"), indent=1)
+import os
+tag = os.environ.get("CRA5_PROF_TAG", "r03")
+json.dump(out, open(f"gpurun_out/{tag}/{tag}_mfma_util.json", "w"), indent=1)
 PY
