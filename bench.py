@@ -299,6 +299,10 @@ def main():
     rank, world, local = D.init_from_env("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("CRA5_SHARE_GPU") == "1":
+        # tests on a 1-GPU box: N ranks (gloo collectives) share the visible GPUs - every piece of the N > 1 job but
+        # the multi-GPU RCCL communicator runs for real (self-launch, sharding, per-rank pipelines, the stats gather)
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     numa = None
@@ -398,6 +402,8 @@ def main():
     # every frame of the job is accounted for exactly once, on every rank
     assert stats[:, 0].tolist() == list(range(world * args.steps)), "gathered stats do not cover the frame set"
 
+    if rank == 0 and os.environ.get("CRA5_BENCH_STATS_OUT"):
+        json.dump(stats.cpu().tolist(), open(os.environ["CRA5_BENCH_STATS_OUT"], "w"))
     total_frames = world * args.steps
     fps = total_frames / elapsed
     result = {

@@ -29,12 +29,23 @@ def init_from_env(device_type="cuda"):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "nccl" if device_type == "cuda" else "gloo"
+        if os.environ.get("CRA5_DIST_BACKEND"):          # tests / emergencies: force "gloo"
+            backend = os.environ["CRA5_DIST_BACKEND"]
         kw = {}
-        if device_type == "cuda":
+        if backend == "nccl":
             torch.cuda.set_device(local)
-            kw["device_id"] = torch.device("cuda", local)   # binds the RCCL communicator to this rank's GPU
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+            kw["device_id"] = torch.device("cuda", local)   # binds the RCCL communicator to this rank's GPU (eager init)
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("CRA5_DIST_TIMEOUT_S", "600"))), **kw)
     return rank, world, local
+
+
+def _coll_device(device):
+    """Collectives run on the device for RCCL ("nccl") and on the host for gloo (CPU tests, CRA5_DIST_BACKEND=gloo)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")
+    return device
 
 
 def _parse_cpulist(text):
@@ -133,6 +144,7 @@ def frame_stats(frame_id, strings):
 def gather_stats(rows, device):
     """all_gather of the per-rank stats (padded to the max per-rank frame count; -1 rows are
     padding).  Returns an int64 tensor [n_frames_total, 4] sorted by frame id on every rank."""
+    device = _coll_device(device)
     t = torch.tensor(rows, dtype=torch.int64, device=device).reshape(-1, len(STATS_FIELDS))
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return t[torch.argsort(t[:, 0])] if t.numel() else t
@@ -158,6 +170,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)

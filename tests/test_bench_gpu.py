@@ -65,3 +65,30 @@ def test_bench_self_launch_rccl_single_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert d["collectives"]["backend"] == "nccl" and d["config"]["host"]["self_launched"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu_frames_and_streams_match_one_rank(tmp_path):
+    """configs[3] in miniature on the hardware at hand: `python bench.py --gpus 2` (self-launched, 2 ranks) with both
+    ranks on the one visible GPU and gloo for the stats gather (RCCL refuses two ranks on one device).  Every frame of
+    the job is coded exactly once, rank 1 codes frames [K, 2K) with seeds 1000 + f, and the per-frame stream sizes and
+    CRCs equal those of a single-rank run over the same 2K frames - sharding changes who codes a frame, not its bytes."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--warmup", "1", "--settle-batches", "0",
+            "--roofline-steps", "1", "--no-cpu-baseline", "--no-api-sample", "--no-kernel-timer", "--inflight", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    s2, s1 = str(tmp_path / "two.json"), str(tmp_path / "one.json")
+    p = subprocess.run(base + ["--gpus", "2", "--steps", "3"], cwd=ROOT, capture_output=True, text=True, timeout=1200,
+                       stdin=subprocess.DEVNULL,
+                       env=dict(env, CRA5_SHARE_GPU="1", CRA5_DIST_BACKEND="gloo", CRA5_BENCH_STATS_OUT=s2))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["collectives"]["backend"] == "gloo" and d["value"] > 0
+    assert d["config"]["host"]["self_launched"] is True and d["config"]["host"]["frame_threads_total"] == 6
+    p = subprocess.run(base + ["--gpus", "1", "--steps", "6"], cwd=ROOT, capture_output=True, text=True, timeout=1200,
+                       stdin=subprocess.DEVNULL, env=dict(env, CRA5_BENCH_STATS_OUT=s1))
+    assert p.returncode == 0, p.stderr[-3000:]
+    two, one = json.load(open(s2)), json.load(open(s1))
+    assert [r[0] for r in two] == list(range(6))
+    assert two == one
