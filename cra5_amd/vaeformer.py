@@ -221,6 +221,37 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+class _SlotGate:
+    """At most `n` frames inside a GPU phase at a time; a waiter with the smaller `prio` number goes first (FIFO among
+    equals).  The encode-side phase (g_a: the longest chain of host + GPU work still ahead of the frame) outranks the
+    decode-side one (g_s: nothing after it): in a K-frame job the last frames' g_a then never queues behind earlier
+    frames' g_s, whose kernels fill the GPU while those last frames sit in their host rANS phases - a shorter drain."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self._free = int(n)
+        self._cv = threading.Condition()
+        self._waiters = []      # (prio, ticket)
+        self._ticket = 0
+
+    def acquire(self, prio=0):
+        with self._cv:
+            self._ticket += 1
+            me = (prio, self._ticket)
+            self._waiters.append(me)
+            while not (self._free > 0 and min(self._waiters) == me):
+                self._cv.wait()
+            self._waiters.remove(me)
+            self._free -= 1
+            if self._free > 0 and self._waiters:
+                self._cv.notify_all()
+
+    def release(self):
+        with self._cv:
+            self._free += 1
+            self._cv.notify_all()
+
+
 class VAEformer(nn.Module):
     def __init__(self, model_version, embed_dim=None, z_channels=None, y_channels=None, sample_posterior=None,
                  pretrained_vae=None, frozen_encoder=None, ddconfig=None, priorconfig=None,
@@ -288,6 +319,9 @@ class VAEformer(nn.Module):
         # y symbols are resolved against the CDF tables by a device kernel (same byte stream)
         self.resolve_on_gpu = os.environ.get("CRA5_RESOLVE_GPU", "1") != "0"
         self._gpu_sem = None
+        # order of the frames waiting for a GPU-phase slot: "g1" (default) encode-side phases first, "g3" decode-side
+        # phases first, "fifo" arrival order (see _SlotGate)
+        self.gpu_prio = os.environ.get("CRA5_GPU_PRIO", "g1")
         # the ~1 ms h_s phase between the two host phases of a decode does not queue for a slot
         self.light_bypass = os.environ.get("CRA5_LIGHT_BYPASS", "1") != "0"
         self.light_priority = os.environ.get("CRA5_LIGHT_PRIORITY", "1") != "0"
@@ -644,7 +678,7 @@ class VAEformer(nn.Module):
 
     # ---- GPU phases -------------------------------------------------------------------------
     @contextlib.contextmanager
-    def _gpu_phase(self, light=False):
+    def _gpu_phase(self, light=False, prio=1):
         """One frame's GPU phase (a run of kernel launches ended by a stream sync, which the
         device->host hand-off to the entropy coder needs anyway).  When several frames are in
         flight (cra5_amd/pipeline.py) phases of different frames take turns on the GPU at this
@@ -660,8 +694,8 @@ class VAEformer(nn.Module):
                     with self._gpu_lock:
                         sem = self._gpu_sem
                         if sem is None or sem[0] != self.gpu_slots:
-                            sem = self._gpu_sem = (self.gpu_slots, threading.BoundedSemaphore(self.gpu_slots))
-                sem[1].acquire()
+                            sem = self._gpu_sem = (self.gpu_slots, _SlotGate(self.gpu_slots))
+                sem[1].acquire(prio if self.gpu_prio == "g1" else (-prio if self.gpu_prio == "g3" else 0))
             t1 = time.perf_counter() if log is not None else 0.0
             try:
                 if light and self.light_priority:
@@ -766,7 +800,7 @@ class VAEformer(nn.Module):
         host phase (two rANS streams).  Either x [C,H,W] or y [L,Hp,Wp]."""
         self.entropy_bottleneck._check()
         self.gaussian_conditional._check()
-        with self._gpu_phase():
+        with self._gpu_phase(prio=0):
             if y is None:
                 y = self._encode_y_frame(x, mean=mean, std=std)
             s = self._latent_side_frame(y.contiguous())
@@ -831,7 +865,7 @@ class VAEformer(nn.Module):
             idx_h = self._to_host("idx", idx)
         y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
         gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
-        with self._gpu_phase():
+        with self._gpu_phase(prio=2):
             y_sym = y_host.to(self.device, non_blocking=True)
             y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym, want=("y_hat",))["y_hat"]
             if not reconstruct:

@@ -242,3 +242,49 @@ def test_synth_is_deterministic():
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert synth.synth_tensor("gaussian_conditional._offset", (0,), 7) is None
     assert torch.equal(synth.synth_frame(3, 5, 4, 6), synth.synth_frame(3, 5, 4, 6))
+
+
+def test_gpu_phase_slot_gate_orders_waiters_by_priority():
+    """vaeformer._SlotGate: at most n holders; among the waiters the smaller priority number goes first, FIFO among
+    equals (encode-side GPU phases ahead of decode-side ones in the frame pipeline)."""
+    import threading
+    import time
+    from cra5_amd.vaeformer import _SlotGate
+    g = _SlotGate(2)
+    g.acquire(1)
+    g.acquire(1)
+    order, lock = [], threading.Lock()
+
+    def worker(prio, name):
+        g.acquire(prio)
+        with lock:
+            order.append(name)
+        time.sleep(0.005)
+        g.release()
+    ts = [threading.Thread(target=worker, args=a) for a in ((2, "d1"), (0, "e1"), (2, "d2"), (1, "m"), (0, "e2"))]
+    for t in ts:
+        t.start()
+        time.sleep(0.02)          # arrival order = list order
+    g.release()
+    g.release()
+    for t in ts:
+        t.join(timeout=10)
+    assert order[:2] == ["e1", "e2"] and order[2] == "m" and order[3:] == ["d1", "d2"]
+    # the gate is reusable and never lets more than n in
+    inside, peak = [0], [0]
+
+    def burst():
+        g.acquire(0)
+        with lock:
+            inside[0] += 1
+            peak[0] = max(peak[0], inside[0])
+        time.sleep(0.002)
+        with lock:
+            inside[0] -= 1
+        g.release()
+    ts = [threading.Thread(target=burst) for _ in range(12)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=10)
+    assert peak[0] == 2
