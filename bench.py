@@ -397,6 +397,16 @@ def main():
     ops.TIMER = None
     rows = [D.frame_stats(my_frames[i], out["strings"]) for i, (out, _) in enumerate(results)]
     assert all(bool(ok) for _, ok in results)
+    # frames that re-use a pool tensor must reproduce its streams byte for byte (sizes + CRC): a race or a
+    # non-deterministic reduction anywhere in the path would show up here (96-step default: every tensor coded 4 times)
+    first_seen = {}
+    for i, row in enumerate(rows):
+        key = seed_of_step[i]
+        if key in first_seen:
+            assert row[1:] == first_seen[key], f"frame of seed {key} coded differently on re-use: {row[1:]} vs {first_seen[key]}"
+        else:
+            first_seen[key] = row[1:]
+    repeats_checked = len(rows) - len(first_seen)
     elapsed = D.max_over_ranks(elapsed, dev)
     stats = D.gather_stats(rows, dev)  # RCCL all-gather of per-frame bitstream stats
     # every frame of the job is accounted for exactly once, on every rank
@@ -432,6 +442,7 @@ def main():
                         "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                         "data_path": "none (frames are independent)", "after_timed_region": "all_gather of int64[K,4] stats"},
         "bytes_per_frame": float(stats[:, 1:3].sum().item()) / max(total_frames, 1),
+        "determinism_check": {"repeated_frames_with_identical_streams_rank0": repeats_checked},
         "model_tflops": FLOP_PER_FRAME * fps / 1e12,
         # whole-path algorithmic rate against the engine's MFMA ceiling (SURVEY 8d "report both")
         "mfma_fraction_end_to_end": FLOP_PER_FRAME * fps / world / (
