@@ -249,6 +249,37 @@ def test_global_attention_balanced_schedule(dev):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("H,W,heads", [(60, 120, 16), (64, 64, 32), (48, 160, 16)])
+def test_global_attention_balanced_schedule_other_shapes(dev, H, W, heads):
+    """Other plans of the balanced schedule: 7200 tokens x 16 heads (225 wave-tiles = 16 slots x 14 + ONE leftover tile,
+    passes of 12 + 2), 4096 tokens x 32 heads (8 slots x 16, no leftover: 12 + 4), 7680 x 16 (15 per slot: 12 + 3) -
+    against the plain launch: identical on the full-pass tokens, within fp32 noise on the key-split leftover ones."""
+    C, N = 64 * heads, H * W
+    nb = ops.attention_workspace_bytes(N, heads)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    if cus != 256:
+        pytest.skip("plans below are written out for 256 CUs")
+    groups = cus // heads
+    base, rem = (N // 32) // groups, (N // 32) % groups
+    assert base >= 12 and nb == heads * rem * groups * 32 * 68 * 4
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    qkv = torch.randn(N, 3 * C, generator=g)
+    qkv[:, :2 * C] *= 1.5
+    qs = ops.split_f16(qkv.to(dev))
+    pad = ops.split_f16(torch.zeros(1, 3 * C, device=dev))
+    plain = ops.window_attention_split(qs, pad, heads, H, W, H, W, out=torch.empty(N, C, device=dev))
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    out = torch.full((N, C), float("nan"), device=dev)
+    ops.window_attention_split(qs, pad, heads, H, W, H, W, out=out, workspace=ws)
+    torch.cuda.synchronize()
+    n_full = base * groups * 32
+    assert torch.isfinite(out).all() and torch.equal(out[:n_full], plain[:n_full])
+    if rem:
+        e = rmse(out[n_full:], plain[n_full:])
+        print(f"balanced attention {H}x{W}, {heads} heads: {rem} leftover tile(s), rmse vs plain {e:.2e}")
+        assert e < 1e-6
+
+
 def test_attention_split_softmax_spike(dev):
     """Late dominant key: forces the (exactly skipped / taken) online-softmax rescale branch."""
     H, W, C, heads = 8, 72, 64, 1
