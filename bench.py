@@ -303,6 +303,8 @@ def main():
         # tests on a 1-GPU box: N ranks (gloo collectives) share the visible GPUs - every piece of the N > 1 job but
         # the multi-GPU RCCL communicator runs for real (self-launch, sharding, per-rank pipelines, the stats gather)
         local = local % torch.cuda.device_count()
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"--gpus {args.gpus}: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     numa = None
