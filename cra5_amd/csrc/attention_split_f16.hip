@@ -14,8 +14,8 @@
 //                    32 VGPRs for the whole kernel, K fragments are ds_read_b128 from a
 //                    [plane][32 keys][64 d] LDS image (row stride 144 B: conflict-free);
 //   softmax          lane (q, h) owns 16 scores of ITS query: log2-domain online softmax
-//                    (p = exp2(s*c - m), c = scale*log2 e folded into one FMA), exact skip of
-//                    the O rescale when no running max moved in the wave;
+//                    (p = exp2(s*c - m), c = scale*log2 e folded into one FMA), the running max m
+//                    DEFERRED: O / l are rescaled only when a tile max exceeds m by more than 2^8;
 //   O^T += V^T . P^T 12 MFMAs: the 16 P values a lane holds ARE its B-operand k-slots (the
 //                    reduction index may be visited in any order: slot (t, j) of lane half h is
 //                    key (r&3)+8(r>>2)+4h with r = 8t+j), split to hi/lo f16 in registers; V^T
@@ -346,8 +346,17 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     // tile j's running max is known before its softmax starts (mloc was reduced in the shadow of
     // the previous tile's PV MFMAs), so the rare O rescale sits at the top and everything below
     // is ONE basic block the scheduler can interleave.
-    const float m_new = fmaxf(m_run, mloc);
-    if (!__all(m_new == m_run)) {   // exact: skip the rescale when no max moved in this wave
+    // DEFERRED running max: m_run moves (and O, l are rescaled) only when some query of the wave saw a tile max more
+    // than DEFER_LOG2 above it; until then p = exp2(s c - m_run) may exceed 1, by at most 2^8 - exact in the hi / lo
+    // f16 split (its precision is relative; 256 is far inside the f16 range) and in the fp32 accumulators, and O / l
+    // carry the same scale, so the result is the softmax whatever reference point the exponentials use.  A new record
+    // among the first k keys has probability 1 / k per query: with 32 queries per wave the exact rule (rescale
+    // whenever any running max moved) fired on ~38 % of the 324 key tiles of the global launch and on nearly every
+    // one of a window's 18; with the threshold it fires on the first tile or two.  (m_run = -inf at the start: the
+    // difference is +inf, the branch is taken, alpha = exp2(-inf) = 0 scales the zero accumulators.)
+    constexpr float DEFER_LOG2 = 8.0f;
+    if (!__all(mloc - m_run <= DEFER_LOG2)) {
+      const float m_new = fmaxf(m_run, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -356,6 +365,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
         for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       m_run = m_new;
     }
+    const float m_new = m_run;   // reference point of this tile's exponentials
     // ---- tile j+1's 12 score MFMAs, interleaved with tile j's softmax VALU work
     // (past the last tile the scores of a stale K buffer are computed and discarded.)
     CRA5_SCORES(s_next, kb);

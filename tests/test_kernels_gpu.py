@@ -280,14 +280,17 @@ def test_global_attention_balanced_schedule_other_shapes(dev, H, W, heads):
         assert e < 1e-6
 
 
-def test_attention_split_softmax_spike(dev):
-    """Late dominant key: forces the (exactly skipped / taken) online-softmax rescale branch."""
+@pytest.mark.parametrize("boost", [4.0, 0.5, 1.0])
+def test_attention_split_softmax_spike(dev, boost):
+    """Late dominant key.  boost 4: its score is ~46 log2 units above the running max -> the O / l rescale branch is
+    taken; boost 0.5 / 1: ~6 / ~11.5 units -> below / just above the deferral threshold (2^8): below it the running
+    max stays put and that key's p = exp2(s - m) is ~55 (> 1), exact in the hi / lo split."""
     H, W, C, heads = 8, 72, 64, 1
     N = H * W
     g = torch.Generator().manual_seed(3)
     qkv = torch.randn(N, 3 * C, generator=g)
     qkv[:, C:2 * C] *= 0.1
-    qkv[500, C:2 * C] = qkv[17, :C] * 4.0
+    qkv[500, C:2 * C] = qkv[17, :C] * boost
     q, k, v = qkv[:, :C].double(), qkv[:, C:2 * C].double(), qkv[:, 2 * C:].double()
     ref = torch.softmax((q * C ** -0.5) @ k.t(), -1) @ v
     qs = ops.split_f16(qkv.to(dev))
