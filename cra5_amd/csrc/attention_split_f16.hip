@@ -290,12 +290,27 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // + buf*VBUF + plane*VPL + (16*t + 8*a)*VS + 32*dt
 
   // cross-half max: lanes l and l+32 own the two halves of one query's 32 scores
+// (the final v_max_f32 sits INSIDE the asm: `fmaxf` on values hipcc cannot prove canonical - asm outputs, like MFMA
+// results - gets a canonicalising `v_max x, x, x` per operand first: 4 of them per key tile in the ISA of round 2)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_XHALF_MAX(X)                                                                 \
   ({                                                                                      \
-    float a_ = (X), b_ = (X);                                                             \
-    asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a_), "+v"(b_));              \
-    fmaxf(a_, b_);                                                                        \
+    float a_ = (X), b_ = (X), r_;                                                         \
+    asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1\n\ts_nop 1\n\tv_max_f32_e32 %2, %0, %1" \
+        : "+v"(a_), "+v"(b_), "=v"(r_));                                                  \
+    r_;                                                                                   \
   })
+// max of two VALU results (never of raw MFMA registers: no hazard wait states are inserted for inline asm)
+#define CRA5_MAX2_VALU(A, B)                                                              \
+  ({                                                                                      \
+    float r_;                                                                             \
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r_) : "v"(A), "v"(B));                          \
+    r_;                                                                                   \
+  })
+#else
+#define CRA5_XHALF_MAX(X) (X)
+#define CRA5_MAX2_VALU(A, B) fmaxf((A), (B))
+#endif
 #if !defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_TILE_MAX(S)                                                                  \
   ({                                                                                      \
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     const float a_ = CRA5_MAX3(S[0], S[1], S[2]), b_ = CRA5_MAX3(S[3], S[4], S[5]), c_ = CRA5_MAX3(S[6], S[7], S[8]); \
     const float d_ = CRA5_MAX3(S[9], S[10], S[11]), e_ = CRA5_MAX3(S[12], S[13], S[14]);     \
     const float f_ = CRA5_MAX3(a_, b_, c_), g_ = CRA5_MAX3(d_, e_, S[15]);                   \
-    CRA5_XHALF_MAX(fmaxf(f_, g_)) * cexp; /* cexp > 0: max commutes with the scale */      \
+    CRA5_XHALF_MAX(CRA5_MAX2_VALU(f_, g_)) * cexp; /* cexp > 0: max commutes with the scale */ \
   })
 #endif
 
