@@ -492,22 +492,56 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     }
     return;
   }
-  if (q_tok >= 0) {
+  // Output.  A query's row is split across the two half-waves: lane (q, h) owns d = 32 t + 8 g + 4 h + (0..3) for
+  // g = 0..3.  Stored as they are, that is 16 eight-byte stores per lane for the split layout - and a row-per-lane
+  // store tail is ISSUE-bound (MI355X_MICROARCH.md: half the instructions at the same bytes = half the tail).  One
+  // v_permlane32_swap per dword turns the groups (g, g + 1) of the two half-waves into 16 contiguous bytes per lane:
+  // lanes 0-31 get columns 16 p .. 16 p + 7 of the pair, lanes 32-63 the next eight (8 sixteen-byte stores per lane).
+  {
     const float inv = 1.0f / l_tot;
-    float *orow = out ? out + (size_t)q_tok * C + hoff : nullptr;
-    unsigned short *srow = out_s ? out_s + (size_t)q_tok * 2 * Kp_out : nullptr;
+    const bool live = q_tok >= 0;
+    float *orow = (out && live) ? out + (size_t)q_tok * C + hoff : nullptr;
+    unsigned short *srow = (out_s && live) ? out_s + (size_t)q_tok * 2 * Kp_out : nullptr;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int d = 32 * t + 8 * gq + 4 * h;
-        float4 v;
-        v.x = o[t][4 * gq + 0] * inv;
-        v.y = o[t][4 * gq + 1] * inv;
-        v.z = o[t][4 * gq + 2] * inv;
-        v.w = o[t][4 * gq + 3] * inv;
-        if (orow) *reinterpret_cast<float4 *>(orow + d) = v;
-        if (srow) cra5_store_split4(srow, hoff + d, v.x, v.y, v.z, v.w);
+      for (int pr = 0; pr < 2; ++pr) {
+        float va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          va[k] = o[t][4 * (2 * pr) + k] * inv;
+          vb[k] = o[t][4 * (2 * pr + 1) + k] * inv;
+        }
+        if (orow) {
+          *reinterpret_cast<float4 *>(orow + 32 * t + 16 * pr + 4 * h) = make_float4(va[0], va[1], va[2], va[3]);
+          *reinterpret_cast<float4 *>(orow + 32 * t + 16 * pr + 8 + 4 * h) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+        }
+        if (out_s) {   // (wave-uniform: every lane takes part in the swaps, only the stores are per-lane)
+          unsigned ha0, la0, ha1, la1, hb0, lb0, hb1, lb1;
+          cra5_split_pair(va[0], va[1], ha0, la0);
+          cra5_split_pair(va[2], va[3], ha1, la1);
+          cra5_split_pair(vb[0], vb[1], hb0, lb0);
+          cra5_split_pair(vb[2], vb[3], hb1, lb1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRA5_SWAP32(A, B)                                                  \
+  {                                                                        \
+    const auto r_ = __builtin_amdgcn_permlane32_swap((A), (B), false, false); \
+    (A) = r_[0];                                                           \
+    (B) = r_[1];                                                           \
+  }
+          CRA5_SWAP32(ha0, hb0);
+          CRA5_SWAP32(ha1, hb1);
+          CRA5_SWAP32(la0, lb0);
+          CRA5_SWAP32(la1, lb1);
+#undef CRA5_SWAP32
+#endif
+          if (srow) {
+            const int c0 = hoff + 32 * t + 16 * pr + 8 * h;          // first of this lane's 8 columns after the swap
+            unsigned short *sp = srow + (c0 >> 5) * 64 + (c0 & 31);
+            *reinterpret_cast<uint4 *>(sp) = make_uint4(ha0, ha1, hb0, hb1);
+            *reinterpret_cast<uint4 *>(sp + 32) = make_uint4(la0, la1, lb0, lb1);
+          }
+        }
       }
   }
 }
