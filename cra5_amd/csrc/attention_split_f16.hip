@@ -498,8 +498,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // v_permlane32_swap per dword turns the groups (g, g + 1) of the two half-waves into 16 contiguous bytes per lane:
   // lanes 0-31 get columns 16 p .. 16 p + 7 of the pair, lanes 32-63 the next eight (8 sixteen-byte stores per lane).
   {
-    const float inv = 1.0f / l_tot;
     const bool live = q_tok >= 0;
+    const float inv = live ? 1.0f / l_tot : 0.0f;   // (dead lanes take part in the swaps below: keep their values finite)
     float *orow = (out && live) ? out + (size_t)q_tok * C + hoff : nullptr;
     unsigned short *srow = (out_s && live) ? out_s + (size_t)q_tok * 2 * Kp_out : nullptr;
 #pragma unroll
