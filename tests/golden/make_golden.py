@@ -206,6 +206,9 @@ def run_e2e(net, x, yhat_synth, step_lat, step_img, tag, full_ints=False):
         z, "symbols", net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)).numpy().astype(np.int32)
     if o["z_sym"].size > 20000:
         o["z_sym_hist"] = np.bincount((o["z_sym"].reshape(-1) + 64).clip(0, 128), minlength=129)
+        if full_ints:       # EVERY z symbol: a consumer can inject the reference's z_hat into its own h_s
+            assert np.abs(o["z_sym"]).max() < 32768
+            o["z_sym_full"] = o["z_sym"].reshape(-1).astype(np.int16)
         o["z_sym"] = o["z_sym"].reshape(-1)[::13]
     params = net.h_s(z_hat)
     scales, means = params.chunk(2, 1)
@@ -354,7 +357,9 @@ def stage_thin():
     net = build_thin()
     load_synth(net, seed=7)
     x = synth.synth_frame(8, seed=2).unsqueeze(0)
-    o = run_e2e(net, x, synth_yhat(16, 5), step_lat=37, step_img=1009, tag="thin")
+    # (round 4: full_ints - every CDF index / y symbol of the reference run, so that the documented flip case of this
+    # frame is pinned element-wise: exactly which index differs, and the reference's integers through the product coder)
+    o = run_e2e(net, x, synth_yhat(16, 5), step_lat=37, step_img=1009, tag="thin", full_ints=True)
     np.savez_compressed(os.path.join(HERE, "thin_e2e.npz"), **o)
     print("thin done")
 
@@ -363,8 +368,14 @@ def stage_full():
     net = VAEformer(268).eval()
     load_synth(net, seed=7)
     x = synth.synth_frame(268, seed=2).unsqueeze(0)
-    o = run_e2e(net, x, synth_yhat(256, 5), step_lat=499, step_img=99991, tag="full")
+    o = run_e2e(net, x, synth_yhat(256, 5), step_lat=499, step_img=99991, tag="full", full_ints=True)
+    # round 4: every integer of the reference's frame (z symbols, CDF indexes, y symbols) in a file of its own, so
+    # that the full-size comparisons no longer depend on the product reproducing all 165 888 z symbols: the test
+    # injects the reference's z_hat into the product's h_s and the reference's (index, symbol) pairs into its coder
+    ints = {k: o.pop(k) for k in ("z_sym_full", "idx_full", "sym_full")}
+    ints["y_string_sha256"], ints["y_string_len"], ints["z_string"] = o["y_string_sha256"], o["y_string_len"], o["z_string"]
     np.savez_compressed(os.path.join(HERE, "full268.npz"), **o)
+    np.savez_compressed(os.path.join(HERE, "full268_ints.npz"), **ints)
     print("full done")
 
 

@@ -41,6 +41,35 @@ def synth_yhat(latent, seed):
     return torch.round(2.0 * torch.randn(1, latent, 72, 144, generator=g)) + torch.randn(1, latent, 72, 144, generator=g)
 
 
+
+def _inject_reference_zhat(net, z_sym_all, dev):
+    """h_s of the PRODUCT on the REFERENCE's z_hat: the reference's integer z symbols (every one of them is in the
+    fixture) + the medians = `quantize(z, "dequantize", medians)` of entropy_models.py:152-179.  Takes the product's own
+    h_a / round() out of the comparison: means / scales / CDF indexes are then held to the float tolerance on EXACTLY the
+    input the reference's h_s saw (vaeformer.py:350-376), whatever rounding flips the end-to-end run has."""
+    cz = net.entropy_bottleneck.channels
+    med = net.entropy_bottleneck.quantiles.detach()[:, 0, 1].reshape(cz, 1).float().to(dev)
+    z_hat = torch.from_numpy(np.asarray(z_sym_all).reshape(cz, -1).astype(np.float32)).to(dev) + med
+    scales, means = net._h_s_frame(z_hat.contiguous())
+    return scales.contiguous(), means.contiguous()
+
+
+def _explained_flips(name, got, ref, value, boundary_of, tol):
+    """Element-wise integer comparison.  Every mismatch must be a step of exactly 1 AND sit within `tol` of the boundary
+    it crossed (value = the product's float, boundary_of(lower integer) = the threshold between the two integers):
+    a rounding flip is float noise on a discontinuous function, anything else is a bug.  Returns the flip count."""
+    got, ref = np.asarray(got).reshape(-1).astype(np.int64), np.asarray(ref).reshape(-1).astype(np.int64)
+    bad = np.nonzero(got != ref)[0]
+    if bad.size:
+        step = np.abs(got[bad] - ref[bad])
+        assert step.max() == 1, f"{name}: {int((step > 1).sum())} mismatches by more than one step"
+        v = np.asarray(value, dtype=np.float64).reshape(-1)[bad]
+        b = boundary_of(np.minimum(got[bad], ref[bad]))
+        d = np.abs(v - b) / np.maximum(1.0, np.abs(b))
+        assert d.max() <= tol, f"{name}: a flipped element sits {d.max():.2e} from its boundary (tolerance {tol:.0e})"
+    return int(bad.size)
+
+
 @pytest.fixture(scope="module")
 def thin(dev):
     net = VAEformer(0, **synth.thin_model_kwargs())
@@ -127,27 +156,36 @@ def test_thin_roundtrip_and_bitstreams(thin, thin_side, dev, golden_dir, tmp_pat
     #     product differs from the reference in 1 of 165 888 CDF indexes (within float tolerance), so here the
     #     comparison is reported through the ledger; it RUNS, un-conditionally, on the second fixture frame
     #     (test_thin_b_* below).
-    same_ints = (torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1)))
-    sha = hashlib.sha256(y_str).digest()
-    hist = np.bincount((s["y_sym"].cpu().numpy().reshape(-1) + 256).clip(0, 512), minlength=513)
-    idx_hist = np.bincount(s["idx"].cpu().numpy().reshape(-1), minlength=64)
-    idx_l1 = int(np.abs(idx_hist - g["idx_hist"]).sum())
-    same_y = np.array_equal(hist, g["sym_hist"]) and idx_l1 == 0
-    print(f"thin streams vs reference-python streams: z integers identical {same_ints}, y integers identical {same_y}")
-    if same_ints:
-        assert z_str == g["z_string"].tobytes()
-        ledger.ran("thin frame a (seed 2): z stream == reference-written z stream")
-    else:
-        ledger.not_applicable("thin frame a (seed 2): z stream == reference-written z stream", "z symbols differ")
-    if same_y:
-        assert sha == g["y_string_sha256"].tobytes()
+    # z symbols of this frame: identical to the reference's, all of them (a regression here fails, it does not move to a
+    # ledger line), hence the z stream is the reference-written one
+    assert torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1))
+    assert z_str == g["z_string"].tobytes()
+    ledger.ran("thin frame a (seed 2): z stream == reference-written z stream")
+    # CDF indexes / y symbols element-wise against the reference's (idx_full / sym_full, round 4): the documented flip
+    # case is ONE index, one step, with the scale within 1e-5 of the table entry it crossed; no symbol flips
+    table = gc.scale_table.double().cpu().numpy()
+    sc_np = np.maximum(s["scales"].double().cpu().numpy(), thin._scale_bound())
+    n_iflip = _explained_flips("thin a CDF indexes", s["idx"].cpu().numpy(), g["idx_full"], sc_np,
+                               lambda k: table[np.clip(k, 0, table.size - 1)], 1e-5)
+    resid = (y[0].double() - s["means"].double()).cpu().numpy()
+    n_sflip = _explained_flips("thin a y symbols", s["y_sym"].cpu().numpy(), g["sym_full"], resid, lambda k: k + 0.5, 1e-4)
+    print(f"thin frame a vs the reference run: CDF index flips {n_iflip}, y symbol flips {n_sflip} of {g['idx_full'].size}")
+    assert n_iflip <= 1 and n_sflip == 0        # pinned: round 3 measured exactly (1, 0); more is a regression
+    if n_iflip == 0:
         assert y_str == g["y_string"].tobytes()
         ledger.ran("thin frame a (seed 2): y stream == reference-written y stream")
     else:
         assert abs(len(y_str) - int(g["y_string_len"][0])) <= 64
-        assert idx_l1 <= 4       # <= 2 flipped indexes (each moves two histogram counts)
         ledger.not_applicable("thin frame a (seed 2): y stream == reference-written y stream",
-                              f"documented flip case: index histogram L1 {idx_l1} (the same comparison runs on frame b)")
+                              f"documented flip case: {n_iflip} of {g['idx_full'].size} CDF indexes one step off, scale within "
+                              "1e-5 of the table entry (the same comparison runs on frame b and, below, on the "
+                              "reference's integers)")
+    # the reference's integers through the device resolve kernel + host state-update loop: the reference-written stream
+    sr, raw, esc = ops.rans_resolve_symbols(torch.from_numpy(g["sym_full"].astype(np.int32)).to(dev),
+                                            torch.from_numpy(g["idx_full"].astype(np.int32)).to(dev),
+                                            gc._quantized_cdf, gc._cdf_length, gc._offset)
+    assert ops.rans_encode_resolved(sr.cpu().numpy(), raw.cpu().numpy(), esc.cpu().numpy()) == g["y_string"].tobytes()
+    ledger.ran("thin frame a (seed 2): y stream coded from the reference's integers == reference-written y stream")
     # (5) full decode: x_hat from the stream == decode_latent(y_hat) exactly (deterministic kernels)
     xa = thin.decompress(out["strings"], out["z_shape"])["x_hat"]
     xb = thin.decode_latent(y_hat)
@@ -221,21 +259,30 @@ def test_thin_decodes_the_reference_stream(thin, thin_side, dev, golden_dir, led
     so the integer side is checked first and a mismatch is reported as such, never skipped silently."""
     g = np.load(f"{golden_dir}/thin_e2e.npz")
     _, y, s = thin_side
-    z_same = torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1))
-    idx_same = np.array_equal(np.bincount(s["idx"].cpu().numpy().reshape(-1), minlength=64), g["idx_hist"])
-    if not (z_same and idx_same):
-        # frame a is the documented flip case (1 of 165 888 CDF indexes); the decode of a reference-written stream is
-        # asserted on frame b (test_thin_b_decodes_the_reference_stream)
+    assert torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1))
+    idx_ref = g["idx_full"].astype(np.int32)
+    idx_same = np.array_equal(s["idx"].cpu().numpy().reshape(-1), idx_ref)        # element-wise, not a histogram
+    strings = [[g["y_string"].tobytes()], [g["z_string"].tobytes()]]
+    if idx_same:
+        y_hat = thin.decompress(strings, (18, 36), return_format='latent')
+        ledger.ran("thin frame a (seed 2): reference-written stream decodes on this build")
+    else:
+        # documented flip case (1 of 165 888 indexes, pinned in test_thin_roundtrip_and_bitstreams): decompress() would
+        # desynchronise at that element.  The decoder itself is held to the reference-written stream with the
+        # REFERENCE's indexes injected; the means that de-quantise the symbols are the product's own.
         ledger.not_applicable("thin frame a (seed 2): reference-written stream decodes on this build",
-                              "product and reference disagree on a CDF index of this frame (rounding flip)")
-        return
-    ledger.ran("thin frame a (seed 2): reference-written stream decodes on this build")
-    y_hat = thin.decompress([[g["y_string"].tobytes()], [g["z_string"].tobytes()]], (18, 36), return_format='latent')
+                              "product and reference disagree on one CDF index of this frame (rounding flip)")
+        sym = thin.gaussian_conditional.decode_symbols(strings[0][0], idx_ref)
+        assert np.array_equal(sym, g["sym_full"].astype(np.int32))
+        y_hat = ops.gaussian_conditional(s["scales"].contiguous(), s["means"].contiguous(),
+                                         thin.gaussian_conditional.scale_table,
+                                         sym_in=torch.from_numpy(sym).to(dev).reshape(s["means"].shape),
+                                         want=("y_hat",))["y_hat"].reshape(1, 16, 72, 144)
+        ledger.ran("thin frame a (seed 2): reference-written stream decodes with the reference's CDF indexes injected")
     d = (sub(y_hat, 37) - torch.from_numpy(g["y_hat_sub"])).abs()
     assert float(d.max()) <= 1e-4, float(d.max())     # same symbols + means within fp32 noise
-    sym_hist = np.bincount((torch.round(y_hat[0].reshape(-1) - s["means"].reshape(-1)).int().cpu().numpy() + 256)
-                           .clip(0, 512), minlength=513)
-    assert np.array_equal(sym_hist, g["sym_hist"])
+    sym_dec = torch.round(y_hat[0].reshape(-1) - s["means"].reshape(-1)).int().cpu().numpy()
+    assert np.array_equal(sym_dec, g["sym_full"].astype(np.int32))
 
 
 def test_thin_vs_cpu_oracle(thin, thin_side, dev):
@@ -382,17 +429,56 @@ def test_full268_vs_reference_golden(big, dev, golden_dir, ledger):
     # flips (4.8 for the reference's own fp32-vs-fp64 error of 1.8e-5); each moves 2 histogram counts.
     expected_flips = s["z"].numel() * 2 * 0.8 * e_z
     assert z_hist_l1 <= max(8, 2 * 3 * expected_flips), (z_hist_l1, expected_flips)
-    if z_hist_l1 == 0 and z_flips == 0:
+    # End to end (the product's own z symbols): a flipped z symbol moves every mean / scale by ~1e-3 through h_s, so
+    # means / scales of THIS run are only compared when no symbol flipped; the float comparison proper runs below on
+    # the reference's z_hat, un-conditionally.
+    gi = np.load(f"{golden_dir}/full268_ints.npz")
+    z_all = s["z_sym"].cpu().numpy().reshape(-1)
+    med_np = big.entropy_bottleneck.quantiles.detach()[:, 0, 1].cpu().numpy().astype(np.float64)
+    z_val = s["z"].double().cpu().numpy().reshape(256, -1) - med_np[:, None]
+    n_zflip = _explained_flips("268 z symbols", z_all, gi["z_sym_full"], z_val, lambda k: k + 0.5, 1e-4)
+    assert z_hist_l1 <= 2 * n_zflip
+    print(f"268: z symbol flips end to end {n_zflip} of {z_all.size}, each one step across a .5 boundary within 1e-4")
+    if n_zflip == 0:
         assert e_m <= 1e-5 and e_s <= 1e-5
-        assert idx_mis <= 1 and sym_mis <= 1
-        assert abs(bits_y - g["bits_y"][0]) <= 2e-4 * g["bits_y"][0]
-        ledger.ran("268 full size: means / scales <= 1e-5, sub-sampled idx / symbols equal, bits_y (no z flip)",
-                   f"means {e_m:.1e}, scales {e_s:.1e}")
-    else:
-        assert e_m <= 5e-3 and e_s <= 5e-3   # bounded effect of <= 4 z flips
-        ledger.not_applicable("268 full size: means / scales <= 1e-5 (needs identical z symbols)",
-                              f"z histogram L1 {z_hist_l1}: bounded-flip branch, means {e_m:.1e}, scales {e_s:.1e}; "
-                              "h_s itself is pinned on the synthetic z_hat")
+    # ---- the reference's z_hat injected into the product's h_s --------------------------
+    sc_i, mu_i = _inject_reference_zhat(big, gi["z_sym_full"], dev)
+    e_mi, e_si = rmse(sub(mu_i, 499), g["means_sub"]), rmse(sub(sc_i, 499), g["scales_sub"])
+    print(f"268, reference z_hat injected: means rmse {e_mi:.3e}, scales rmse {e_si:.3e}")
+    assert e_mi <= 1e-5 and e_si <= 1e-5
+    ledger.ran("268 full size: means / scales <= 1e-5 on the reference's z_hat (injected into the product's h_s)",
+               f"means {e_mi:.1e}, scales {e_si:.1e}")
+    gci = ops.gaussian_conditional(sc_i, mu_i, big.gaussian_conditional.scale_table, y=y[0].contiguous(),
+                                   want=("idx", "sym"), scale_bound=big._scale_bound(),
+                                   lik_bound=big.gaussian_conditional.likelihood_bound)
+    table = big.gaussian_conditional.scale_table.double().cpu().numpy()
+    sc_np = np.maximum(sc_i.double().cpu().numpy(), big._scale_bound())
+    n_iflip = _explained_flips("268 CDF indexes", gci["idx"].cpu().numpy(), gi["idx_full"], sc_np,
+                               lambda k: table[np.clip(k, 0, table.size - 1)], 1e-5)
+    resid = (y[0].double() - mu_i.double()).cpu().numpy()
+    n_sflip = _explained_flips("268 y symbols", gci["sym"].cpu().numpy(), gi["sym_full"], resid, lambda k: k + 0.5, 1e-4)
+    n_lat = gi["idx_full"].size
+    print(f"268, reference z_hat injected: CDF index flips {n_iflip} / {n_lat} (reference vs its own fp64 run: 8), "
+          f"y symbol flips {n_sflip} / {n_lat} (expected from the y error: {n_lat * 2 * 0.8 * e_y:.0f})")
+    assert n_iflip <= 16                                   # scale within 1e-5 of a table entry: O(10) of 2.65 M
+    assert n_sflip <= max(8, 3 * n_lat * 2 * 0.8 * e_y)    # |y - mu| within the y error of a .5 boundary
+    ledger.ran("268 full size: every CDF index / y symbol vs the reference's, flips explained element-wise",
+               f"{n_iflip} index, {n_sflip} symbol flips of {n_lat}, all one step across a boundary within tolerance")
+    # the reference's integers through the DEVICE resolve kernel + host state-update loop (the frame path's coder):
+    # the stream the reference's compress() wrote, byte for byte (sha256; the CPU twin is tests/test_reference_streams.py)
+    gcm = big.gaussian_conditional
+    sr, raw, esc = ops.rans_resolve_symbols(torch.from_numpy(gi["sym_full"].astype(np.int32)).to(dev),
+                                            torch.from_numpy(gi["idx_full"].astype(np.int32)).to(dev),
+                                            gcm._quantized_cdf, gcm._cdf_length, gcm._offset)
+    y_ref_stream = ops.rans_encode_resolved(sr.cpu().numpy(), raw.cpu().numpy(), esc.cpu().numpy())
+    assert len(y_ref_stream) == int(gi["y_string_len"][0])
+    assert hashlib.sha256(y_ref_stream).digest() == gi["y_string_sha256"].tobytes()
+    ledger.ran("268 full size: sha256(y stream coded from the reference's integers) == reference-written y stream's",
+               f"{len(y_ref_stream)} bytes through the device resolve kernel + cra5_rans_encode_resolved")
+    z_idx_all = big.entropy_bottleneck._build_indexes((1, 256, 18, 36))
+    assert big.entropy_bottleneck.encode_symbols(gi["z_sym_full"].astype(np.int32), z_idx_all) == g["z_string"].tobytes()
+    ledger.ran("268 full size: z stream coded from the reference's z symbols == reference-written z stream",
+               f"{g['z_string'].size} bytes")
     p = _hs_from_synth(big, dev)
     e_h = rmse(sub(p, 499), g["hs_synth_sub"])
     print(f"268: h_s on synthetic z_hat rmse {e_h:.3e}")
@@ -415,21 +501,14 @@ def test_full268_vs_reference_golden(big, dev, golden_dir, ledger):
                              gc._cdf_length.cpu().numpy(), gc._offset.cpu().numpy())
     assert torch.equal(back.reshape(-1), s["y_sym"].cpu().reshape(-1))
     sym_l1, idx_l1 = int(np.abs(hist - g["sym_hist"]).sum()), int(np.abs(idx_hist - g["idx_hist"]).sum())
-    if z_hist_l1 == 0 and z_flips == 0:
+    # the product's OWN end-to-end streams equal the reference-written ones exactly when no integer flipped (the
+    # comparison on the reference's integers ran above, un-conditionally)
+    if n_zflip == 0:
         assert out["strings"][1][0] == g["z_string"].tobytes()
-        ledger.ran("268 full size: z stream == reference-written z stream", f"{len(out['strings'][1][0])} bytes")
-    else:
-        ledger.not_applicable("268 full size: z stream == reference-written z stream", f"z histogram L1 {z_hist_l1}")
-    if z_hist_l1 == 0 and z_flips == 0 and sym_l1 == 0 and idx_l1 == 0:
-        # identical integers to the reference run: the stream the reference's python wrote is ours
+    if n_zflip == 0 and sym_l1 == 0 and idx_l1 == 0:
         assert hashlib.sha256(out["strings"][0][0]).digest() == g["y_string_sha256"].tobytes()
-        ledger.ran("268 full size: sha256(y stream) == reference-written y stream's")
-    else:
-        ledger.not_applicable("268 full size: sha256(y stream) == reference-written y stream's",
-                              f"2.65 M latents: symbol histogram L1 {sym_l1}, index histogram L1 {idx_l1}, z L1 {z_hist_l1} "
-                              "(the reference flips 2 symbols against its own fp64 run, BASELINE.md section 2); the byte "
-                              "comparison with a reference-written stream runs on thin frame b, and at full size "
-                              "against the oracle coder on the product's own integers (above)")
+    print(f"268 end to end: z flips {n_zflip}, symbol histogram L1 {sym_l1}, index histogram L1 {idx_l1} "
+          "(the reference flips 2 symbols / 8 indexes against its own fp64 run, BASELINE.md section 2)")
     y_hat = big.decompress(out["strings"], out["z_shape"], return_format='latent')
     assert torch.equal(y_hat[0].reshape(-1), s["y_hat"].reshape(-1))
     # decoder, identical y_hat
@@ -488,12 +567,30 @@ def test_quality_159_vs_reference_golden(dev, golden_dir, ledger):
     if z_mis == 0:
         assert e_m <= 1e-5 and e_s <= 1e-5
         assert idx_mis <= 1 and sym_mis <= 1 and flips <= 1 and e_q <= 1e-5
-        ledger.ran("159: means / scales / y_hat <= 1e-5 with identical z symbols", f"means {e_m:.1e}, y_hat {e_q:.1e}")
     else:
-        assert flips <= 2 and e_q <= 5e-3 and e_m <= 5e-3 and e_s <= 5e-3
-        ledger.not_applicable("159: means / scales / y_hat <= 1e-5 (needs identical z symbols)",
-                              f"{z_mis} z symbol flip(s) of {g['z_sym'].size}: bounded-flip branch, means {e_m:.1e}, "
-                              f"y_hat {e_q:.1e}")
+        assert flips <= 2 and e_q <= 5e-3       # end to end: the bounded effect of a few z flips on y_hat
+    # the reference's z_hat (all 165 888 symbols are in the fixture) injected into the product's h_s: means / scales /
+    # y_hat held to the float tolerance on exactly the reference's input, whatever z flips the end-to-end run has
+    sc_i, mu_i = _inject_reference_zhat(net, g["z_sym"], dev)
+    e_mi, e_si = rmse(sub(mu_i, 499), g["means_sub"]), rmse(sub(sc_i, 499), g["scales_sub"])
+    gci = ops.gaussian_conditional(sc_i, mu_i, net.gaussian_conditional.scale_table, y=y[0].contiguous(),
+                                   want=("idx", "sym", "y_hat"), scale_bound=net._scale_bound(),
+                                   lik_bound=net.gaussian_conditional.likelihood_bound)
+    idx_i = int((sub(gci["idx"], 499) != torch.from_numpy(g["idx_sub"])).sum())
+    sym_i = int((sub(gci["sym"], 499) != torch.from_numpy(g["sym_sub"])).sum())
+    di = (sub(gci["y_hat"], 499) - torch.from_numpy(g["y_hat_sub"])).abs()
+    e_qi = float(torch.sqrt((di[di <= 0.5].double() ** 2).mean()))
+    ih = np.bincount(gci["idx"].cpu().numpy().reshape(-1), minlength=64)
+    ih_l1 = int(np.abs(ih - g["idx_hist"]).sum())
+    sh = np.bincount((gci["sym"].cpu().numpy().reshape(-1) + 256).clip(0, 512), minlength=513)
+    sh_l1 = int(np.abs(sh - g["sym_hist"]).sum())
+    print(f"159, reference z_hat injected: means {e_mi:.3e}, scales {e_si:.3e}, y_hat {e_qi:.3e}, sampled idx / symbol "
+          f"flips {idx_i} / {sym_i}, index histogram L1 {ih_l1}, symbol histogram L1 {sh_l1}")
+    assert e_mi <= 1e-5 and e_si <= 1e-5 and e_qi <= 1e-5
+    assert idx_i <= 1 and sym_i <= 1 and int((di > 0.5).sum()) <= 1
+    assert ih_l1 <= 32 and sh_l1 <= max(16, 2 * 3 * y.numel() * 2 * 0.8 * e_y)
+    ledger.ran("159: means / scales / y_hat <= 1e-5 on the reference's z_hat (injected into the product's h_s)",
+               f"means {e_mi:.1e}, y_hat {e_qi:.1e}; end-to-end z flips {z_mis}")
 
 
 def test_api_268_channels_real_stats(big, dev, golden_dir, tmp_path):
