@@ -161,22 +161,19 @@ def cpu_baseline(quality, n_threads):
 
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
-    torch.distributed.run (one process per GPU; 127.0.0.1 rendezvous on a free port).  stdout / stderr are
+    torch.distributed.run (one process per GPU; standalone rendezvous on 127.0.0.1, port chosen by the launcher).  stdout / stderr are
     inherited, so rank 0's JSON line is this process's output; returns the job's exit code."""
-    import socket
     import subprocess
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-    sk.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
     env["CRA5_SELF_LAUNCHED"] = "1"
     # torch.distributed.run forces OMP_NUM_THREADS=1 when it is unset; every rank sizes its own pools from its
     # NUMA share of the cores instead (main())
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // (2 * n))))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous on a port IT picks and keeps (picking a free port here and
+    # closing it again was a bind / close race between concurrent jobs); 127.0.0.1: the container hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env, stdin=subprocess.DEVNULL)
 
 
@@ -185,7 +182,7 @@ def dry_dist(args):
     frame sharding, barrier, max-over-ranks, the all-gather of per-frame stats, one JSON line from rank 0.
     Stand-in streams (the stats only look at bytes).  Used by tests/test_dist_cpu.py."""
     from cra5_amd import dist as D
-    rank, world, local = D.init_from_env("cpu")
+    rank, world, local = D.init_from_env("cpu", numa_bind=not args.no_numa_bind)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cpu = torch.device("cpu")
@@ -197,8 +194,12 @@ def dry_dist(args):
     elapsed = D.max_over_ranks(time.perf_counter() - t0 + 1e-3 * (rank + 1), cpu)
     stats = D.gather_stats(rows, cpu)
     assert stats[:, 0].tolist() == list(range(world * args.steps)), "gathered stats do not cover the frame set"
+    hosts = D.gather_objects(dict(D.host_report(), numa_bind=D.LAST_BIND))
     if rank == 0:
         print(json.dumps({"metric": "dry-dist (no GPU work)", "dry": True, "n_gpus": world, "steps": args.steps,
+                          "host_per_rank": [dict(h, cpus=[h["cpus"][0], h["cpus"][-1]] if h["cpus"] else []) for h in hosts],
+                          "host_cpu_sets_disjoint": _disjoint([h["cpus"] for h in hosts]),
+                          "stats_fields": list(D.STATS_FIELDS),
                           "warmup": args.warmup, "value": world * args.steps / elapsed, "unit": "frames/s",
                           "frames_of_rank0": [my[0], my[-1] + 1] if len(my) else [],
                           "stats_rows": int(stats.shape[0]), "stats_bytes": int(stats[:, 1:3].sum()),
@@ -207,6 +208,15 @@ def dry_dist(args):
               flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def _disjoint(sets):
+    seen = set()
+    for c in sets:
+        if seen & set(c):
+            return False
+        seen |= set(c)
+    return True
 
 
 def rocprof_gemm_frac():
@@ -271,6 +281,8 @@ def main():
                          "slot i %% pool; with --steps <= pool every frame of the job is distinct)")
     ap.add_argument("--dry-dist", action="store_true",
                     help="no GPU work: launch / rendezvous (gloo) / shard / barrier / all-gather / one JSON line only")
+    ap.add_argument("--no-f16-sample", action="store_true",
+                    help="skip the short reduced-precision sample (`precision_f16`: BASELINE configs[4] on this GPU, rank 0, N = 1)")
     ap.add_argument("--no-api-sample", action="store_true",
                     help="skip the reference-named single-frame API sample (`api_single_frame`, rank 0, N = 1)")
     ap.add_argument("--no-numa-bind", action="store_true",
@@ -296,7 +308,9 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only product path")
-    rank, world, local = D.init_from_env("cuda")
+    # (N > 1: the rank is pinned to its GPU's NUMA share of the host cores inside init_from_env, BEFORE the process group
+    # and the HIP runtime start their helper threads - ADVICE r3)
+    rank, world, local = D.init_from_env("cuda", numa_bind=not args.no_numa_bind)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("CRA5_SHARE_GPU") == "1":
@@ -312,9 +326,7 @@ def main():
         # N ranks share the node's host cores.  Pin this rank (its frame threads, its rANS work, its torch CPU pool)
         # to its GPU's NUMA node, an equal share of that node's cores per rank on the node: pinned staging buffers
         # are then allocated node-local and 8 x 12 frame threads do not migrate over both sockets.
-        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        if not args.no_numa_bind:
-            numa = D.bind_rank_to_numa(local, n_local)
+        numa = D.LAST_BIND
         share = len(os.sched_getaffinity(0)) if (numa and numa.get("bound")) else (os.cpu_count() or 8) // world
         torch.set_num_threads(max(1, share // 2))
 
@@ -359,7 +371,10 @@ def main():
     net.precision = args.precision
     # warm-up: W untimed steps (also builds the per-thread workspaces / derived weights)
     net.compress(frames[0])
-    pipe.map(round_trip, [frames[i % pool] for i in range(max(args.warmup, args.inflight))])
+    warm = pipe.map(round_trip, [frames[i % pool] for i in range(max(args.warmup, args.inflight))])
+    # streams of the warm-up frames: the timed region codes the same tensors again and must reproduce them (sizes + CRC)
+    warm_rows = {i % pool: D.frame_stats(0, out["strings"], out.get("n_escape", [-1])[0])[1:] for i, (out, _) in enumerate(warm)}
+    del warm
     # A fresh box runs slow for its first MINUTE, not seconds (power state / clocks of GPU and host, page cache):
     # four consecutive bench processes on a new box measured 22.7, 23.5, 25.1, 26.3 frames/s with the round-1
     # rule (stop when two batches agree within 3 %).  Keep running untimed batches until the best batch time has
@@ -397,22 +412,24 @@ def main():
     D.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
-    rows = [D.frame_stats(my_frames[i], out["strings"]) for i, (out, _) in enumerate(results)]
+    rows = [D.frame_stats(my_frames[i], out["strings"], out.get("n_escape", [-1])[0]) for i, (out, _) in enumerate(results)]
     assert all(bool(ok) for _, ok in results)
     # frames that re-use a pool tensor must reproduce its streams byte for byte (sizes + CRC): a race or a
     # non-deterministic reduction anywhere in the path would show up here (96-step default: every tensor coded 4 times)
-    first_seen = {}
+    first_seen = {1000 + my_frames[0] + slot: r for slot, r in warm_rows.items()}
+    n_warm_keys = len(first_seen)
     for i, row in enumerate(rows):
         key = seed_of_step[i]
         if key in first_seen:
             assert row[1:] == first_seen[key], f"frame of seed {key} coded differently on re-use: {row[1:]} vs {first_seen[key]}"
         else:
             first_seen[key] = row[1:]
-    repeats_checked = len(rows) - len(first_seen)
+    repeats_checked = len(rows) - (len(first_seen) - n_warm_keys)
     elapsed = D.max_over_ranks(elapsed, dev)
     stats = D.gather_stats(rows, dev)  # RCCL all-gather of per-frame bitstream stats
     # every frame of the job is accounted for exactly once, on every rank
     assert stats[:, 0].tolist() == list(range(world * args.steps)), "gathered stats do not cover the frame set"
+    hosts = D.gather_objects(dict(D.host_report(), numa_bind=D.LAST_BIND)) if world > 1 else None
 
     if rank == 0 and os.environ.get("CRA5_BENCH_STATS_OUT"):
         json.dump(stats.cpu().tolist(), open(os.environ["CRA5_BENCH_STATS_OUT"], "w"))
@@ -438,13 +455,24 @@ def main():
                    "distinct_frames_per_rank": pool, "frame_seeds_rank0": [seed_of_step[0], seed_of_step[-1]],
                    "frames_in_flight_per_gpu": args.inflight,
                    "host": {"frame_threads_total": args.inflight * world, "host_threads": os.cpu_count(),
-                            "numa_bind_rank0": numa, "self_launched": os.environ.get("CRA5_SELF_LAUNCHED") == "1"}},
+                            "numa_bind_rank0": numa, "self_launched": os.environ.get("CRA5_SELF_LAUNCHED") == "1",
+                            # N > 1: every rank's CPU mask after the bind, and how many of its threads (frame threads,
+                            # rANS pool, RCCL / HIP helpers) have a mask outside it - must be 0
+                            "per_rank": None if hosts is None else [
+                                {"rank": h["rank"], "n_cpus": h["n_cpus"], "cpu_span": [h["cpus"][0], h["cpus"][-1]] if h["cpus"] else [],
+                                 "threads": h["threads"], "threads_outside_mask": h["threads_outside_mask"],
+                                 "numa_node": (h.get("numa_bind") or {}).get("numa_node")} for h in hosts],
+                            "cpu_sets_disjoint": None if hosts is None else _disjoint([h["cpus"] for h in hosts])}},
         "warmup_settle_frames": settle_frames,
         "collectives": {"initialized": bool(torch.distributed.is_available() and torch.distributed.is_initialized()),
                         "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
-                        "data_path": "none (frames are independent)", "after_timed_region": "all_gather of int64[K,4] stats"},
+                        "data_path": "none (frames are independent)", "after_timed_region": "all_gather of int64[K,5] stats"},
         "bytes_per_frame": float(stats[:, 1:3].sum().item()) / max(total_frames, 1),
-        "determinism_check": {"repeated_frames_with_identical_streams_rank0": repeats_checked},
+        "determinism_check": {"repeated_frames_with_identical_streams_rank0": repeats_checked,
+                              "note": "frames of the timed region whose tensor was coded before (in the warm-up or earlier in "
+                                      "the region) and reproduced its stream sizes, CRC and escape count"},
+        "stats_fields": list(D.STATS_FIELDS),
+        "escape_symbols_per_frame": float(stats[:, 4].clamp(min=0).sum().item()) / max(total_frames, 1),
         "model_tflops": FLOP_PER_FRAME * fps / 1e12,
         # whole-path algorithmic rate against the engine's MFMA ceiling (SURVEY 8d "report both")
         "mfma_fraction_end_to_end": FLOP_PER_FRAME * fps / world / (
@@ -532,14 +560,53 @@ def main():
         result.update(roofline_from(t2.summary(), max(1, args.roofline_steps)))
         if "roofline" in result:
             rp = rocprof_gemm_frac()
-            if rp:   # the committed rocprofv3 summary of this command beside the live HIP-event figure
-                result["roofline"]["frac_rocprof"] = rp["frac"]
-                result["roofline"]["rocprof"] = rp
+            if rp:   # NOT a measurement of this run: the committed rocprofv3 summary of an earlier build, for comparison
+                result["roofline"]["committed_reference"] = dict(
+                    rp, note="pre-recorded profiles/" + rp["file"] + " (rocprofv3 --kernel-trace --stats of the exclusive "
+                             "bench command at the commit that added the file; `git log -1 -- profiles/" + rp["file"] +
+                             "`); everything else in `roofline` was measured by this run")
             result["roofline"]["measured_over"] = (
                 f"a separate un-overlapped pass of {max(1, args.roofline_steps)} frames run right after the timed "
                 "region (HIP events around every launch, on the launch stream, exclusive GPU phases); "
                 "`roofline_timed_region` holds the sampled measurement taken inside the timed region, where "
                 "launches of concurrent frames overlap and per-launch durations are inflated")
+    if rank == 0 and world == 1 and args.precision == "fp32" and not args.no_f16_sample and args.quality == 268 \
+            and net.gemm_mode != "f32":
+        # BASELINE.json configs[4] (reduced precision: plain f16 operands in g_a / g_s, fp32 accumulate, hyper-prior and
+        # GaussianConditional fp32-accurate) on THIS GPU: a short sample outside the timed region - frames/s of the same
+        # pipeline, and the error it buys against the fp32-accurate run on the same frame.  Never part of `value`.
+        try:
+            net.gpu_exclusive = False
+            rm = lambda a, b: float(torch.sqrt(torch.mean((a.double() - b.double()) ** 2)))  # noqa: E731
+            x0 = frames[0]
+            y32 = net.encode_latent(x0, type='float')[0]
+            y_hat = torch.round(y32)
+            xh32 = net.decode_latent(y_hat)
+            net.precision = "f16"
+            y16 = net.encode_latent(x0, type='float')[0]
+            xh16 = net.decode_latent(y_hat)
+            e_y, e_x, y_rms = rm(y16, y32), rm(xh16, xh32), float(torch.sqrt(torch.mean(y32.double() ** 2)))
+            del y32, y16, xh32, xh16, y_hat
+            n16 = 2 * args.inflight
+            pipe.map(round_trip, [frames[i % pool] for i in range(args.inflight)])       # first use of the f16 instantiations
+            torch.cuda.synchronize()
+            t16 = time.perf_counter()
+            r16 = pipe.map(round_trip, [frames[i % pool] for i in range(n16)])
+            torch.cuda.synchronize()
+            t16 = time.perf_counter() - t16
+            assert all(bool(ok) for _, ok in r16)
+            result["precision_f16"] = {
+                "value": n16 / t16, "unit": "frames/s", "frames": n16, "ratio_to_fp32_value": n16 / t16 / fps,
+                "y_rmse_vs_fp32_run": e_y, "y_rms": y_rms, "x_hat_rmse_vs_fp32_run_same_y_hat": e_x,
+                "gate": "BASELINE configs[4]: RMSE within 1e-2..1e-3 of the fp32 path (tests/test_model_gpu.py::"
+                        "test_full268_reduced_precision_mode asserts it against the reference golden)",
+                "what": "same pipeline and frames as the timed region with CRA5_PRECISION=f16 (1 MFMA per product in g_a / "
+                        "g_s GEMMs and attention; h_a / h_s / entropy side unchanged so both sides derive the same CDF "
+                        f"indexes); {n16}-frame region after one warm batch, outside the timed region"}
+        except Exception as ex:  # noqa: BLE001
+            result["precision_f16"] = {"value": None, "error": repr(ex)}
+        finally:
+            net.precision = "fp32"
     if rank == 0 and world == 1 and not args.no_api_sample and args.quality == 268:
         # What a drop-in caller of the REFERENCE-NAMED single-frame methods sees (test.py:14-45 in the reference):
         # encode_era5_as_bin(host array -> .bin on disk) + decode_from_bin(.bin -> x_hat on the device), one frame at

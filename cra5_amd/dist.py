@@ -5,8 +5,13 @@ The path shards by FRAME: hourly snapshots are independen
 (no cross-frame state, one rANS stream pair per frame - entropy_models.py:263-272 in the
 reference), so weights are replicated and there is NO data-path collective.  The single
 exchange is an all-gather of a tiny per-frame stats tensor (bytes of the y / z streams,
-escape count, stream checksum): 32 B per frame, latency-bound, so ring-vs-tree or xGMI
+escape count, stream checksum): 40 B per frame, latency-bound, so ring-vs-tree or xGMI
 link bandwidth is irrelevant for it.
+
+Host side of an N-rank job: `init_from_env` pins the rank to its GPU's NUMA share of the host cores BEFORE the
+process group and the HIP runtime exist (their helper threads inherit the mask; threads that already run are
+re-pinned one by one), finding the GPU's PCI address without a HIP call (KFD topology in sysfs, honouring
+HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES).
 """
 import os
 import zlib
@@ -14,15 +19,23 @@ import zlib
 import torch
 import torch.distributed as dist
 
-STATS_FIELDS = ("frame", "y_bytes", "z_bytes", "crc32")
+STATS_FIELDS = ("frame", "y_bytes", "z_bytes", "crc32", "n_escape")   # SURVEY 8(e); n_escape = -1: not counted
 
 
-def init_from_env(device_type="cuda"):
+LAST_BIND = None    # what bind_rank_to_numa did for this process (bench.py reports it)
+
+
+def init_from_env(device_type="cuda", numa_bind=False):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as set by
-    torch.distributed.run). Returns (rank, world, local_rank)."""
+    torch.distributed.run). Returns (rank, world, local_rank).  numa_bind: pin the rank to its GPU's NUMA share of the
+    host cores first - before init_process_group and before the first HIP call of this function, so that the RCCL
+    proxy threads, the HIP runtime's threads and every later frame thread are created under the mask."""
+    global LAST_BIND
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if numa_bind and world > 1:
+        LAST_BIND = bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     force = os.environ.get("CRA5_FORCE_DIST") == "1"   # exercise the RCCL path with a single rank
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -33,8 +46,11 @@ def init_from_env(device_type="cuda"):
             backend = os.environ["CRA5_DIST_BACKEND"]
         kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            kw["device_id"] = torch.device("cuda", local)   # binds the RCCL communicator to this rank's GPU (eager init)
+            dev_i = local
+            if os.environ.get("CRA5_SHARE_GPU") == "1":    # tests on a 1-GPU box: ranks share the visible GPUs
+                dev_i = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(dev_i)
+            kw["device_id"] = torch.device("cuda", dev_i)   # binds the RCCL communicator to this rank's GPU (eager init)
         import datetime
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=int(os.environ.get("CRA5_DIST_TIMEOUT_S", "600"))), **kw)
@@ -59,14 +75,70 @@ def _parse_cpulist(text):
     return out
 
 
-def gpu_numa_node(local):
-    """NUMA node of GPU `local` from its PCI address (sysfs), or None when it cannot be told."""
+def _visible_physical_index(local):
+    """Physical (ROCr enumeration) index of logical device `local` under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES remapping (integer lists only; UUID forms -> None)."""
+    idx = local
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):   # HIP's list indexes ROCr's
+        v = os.environ.get(var)
+        if v is None or v.strip() == "":
+            continue
+        if var == "CUDA_VISIBLE_DEVICES" and os.environ.get("HIP_VISIBLE_DEVICES"):
+            continue                                      # the two are aliases: apply once
+        try:
+            lst = [int(x) for x in v.split(",") if x.strip() != ""]
+        except ValueError:
+            return None
+        if idx >= len(lst):
+            return None
+        idx = lst[idx]
+    return idx
+
+
+def kfd_gpu_bdfs(root="/sys/class/kfd/kfd/topology/nodes"):
+    """PCI addresses of the GPUs in KFD topology order (= ROCr / HIP enumeration order without visibility masks), read
+    from sysfs: no HIP call, usable before the runtime is initialised.  [] when the topology is not readable."""
+    out = []
     try:
-        p = torch.cuda.get_device_properties(local)
-        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        ids = sorted((d for d in os.listdir(root) if d.isdigit()), key=int)
+    except OSError:
+        return out
+    for d in ids:
+        props = {}
+        try:
+            for line in open(os.path.join(root, d, "properties")):
+                k, _, v = line.strip().partition(" ")
+                props[k] = v
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue                                      # a CPU node
+        loc, dom = int(props.get("location_id", "0") or 0), int(props.get("domain", "0") or 0)
+        out.append("%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+    return out
+
+
+def gpu_numa_node(local, bdfs=None, sys_pci="/sys/bus/pci/devices"):
+    """NUMA node of logical GPU `local` from its PCI address, or None when it cannot be told.  The address comes from
+    the KFD topology + the visibility masks (no HIP call: this runs before the process group / HIP runtime start);
+    torch's device properties are the fallback when HIP is already up."""
+    bdf = None
+    phys = _visible_physical_index(local)
+    bdfs = kfd_gpu_bdfs() if bdfs is None else bdfs
+    if phys is not None and phys < len(bdfs):
+        bdf = bdfs[phys]
+    elif torch.cuda.is_initialized():
+        try:
+            p = torch.cuda.get_device_properties(local)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        except Exception:  # noqa: BLE001
+            bdf = None
+    if bdf is None:
+        return None
+    try:
+        node = int(open(f"{sys_pci}/{bdf}/numa_node").read())
         return node if node >= 0 else None
-    except Exception:  # noqa: BLE001
+    except (OSError, ValueError):
         return None
 
 
@@ -103,27 +175,91 @@ def rank_cpu_set(local, n_local, node=None, node_peers=None, allowed=None, node_
     return out or cpus[k * (len(cpus) // m):(k + 1) * (len(cpus) // m)]
 
 
+def plan_rank_cpus(local, n_local, nodes, allowed, node_cpus_of):
+    """CPU set of rank `local`: pure function (tested on CPU).  nodes[i] = NUMA node of rank i's GPU or None.  If ANY
+    rank's node is unknown, EVERY rank takes an equal share of the allowed CPUs - one consistent rule, so that a
+    node-bound rank and a fallback rank can never be handed overlapping cores."""
+    if any(n is None for n in nodes):
+        return None, rank_cpu_set(local, n_local, None, None, allowed, None)
+    node = nodes[local]
+    same = [i for i in range(n_local) if nodes[i] == node]
+    return node, rank_cpu_set(local, n_local, node, (same.index(local), len(same)), allowed, node_cpus_of(node))
+
+
+def _pin_all_threads(cpus):
+    """sched_setaffinity(0) moves only the calling thread: pin every thread this process already has (OpenMP pool,
+    anything an import started); threads created later inherit the caller's mask."""
+    n = 0
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = []
+    for t in tids:
+        try:
+            os.sched_setaffinity(t, cpus)
+            n += 1
+        except OSError:
+            pass
+    os.sched_setaffinity(0, cpus)
+    return n
+
+
 def bind_rank_to_numa(local, n_local):
-    """Pin this process (all its future threads: the 12 frame threads, the rANS pool) to the CPUs of its
-    GPU's NUMA node, shared equally with the other ranks whose GPU sits on the same node.  Returns a dict
-    describing what was done (reported in bench.py's JSON line)."""
+    """Pin this process - the threads it has and all its future ones (the 12 frame threads, the rANS pool, RCCL's and
+    the HIP runtime's helpers when called before they start) - to the CPUs of its GPU's NUMA node, shared equally
+    with the other ranks whose GPU sits on the same node.  Returns a dict describing what was done (reported in
+    bench.py's JSON line)."""
     info = {"numa_node": None, "cpus": None, "bound": False}
     try:
-        nodes = [gpu_numa_node(i) for i in range(n_local)]
-        node = nodes[local]
-        node_cpus = None
-        peers = None
-        if node is not None:
-            node_cpus = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
-            same = [i for i in range(n_local) if nodes[i] == node]
-            peers = (same.index(local), len(same))
-        cpus = rank_cpu_set(local, n_local, node, peers, None, node_cpus)
+        bdfs = kfd_gpu_bdfs()
+        n_vis = 0
+        while _visible_physical_index(n_vis) is not None and _visible_physical_index(n_vis) < len(bdfs) and n_vis < 64:
+            n_vis += 1
+            if not any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")):
+                n_vis = len(bdfs)
+                break
+        share = os.environ.get("CRA5_SHARE_GPU") == "1" and n_vis > 0     # tests: ranks share the visible GPUs
+        nodes = [gpu_numa_node(i % n_vis if share else i, bdfs) for i in range(n_local)]
+        node, cpus = plan_rank_cpus(
+            local, n_local, nodes, None,
+            lambda nd: _parse_cpulist(open(f"/sys/devices/system/node/node{nd}/cpulist").read()))
         if cpus:
-            os.sched_setaffinity(0, cpus)
-            info.update(numa_node=node, cpus=len(cpus), bound=True, first_cpu=cpus[0], last_cpu=cpus[-1])
+            n_thr = _pin_all_threads(cpus)
+            info.update(numa_node=node, cpus=len(cpus), bound=True, first_cpu=cpus[0], last_cpu=cpus[-1],
+                        threads_pinned=n_thr, before_hip_init=not torch.cuda.is_initialized(),
+                        rule="numa share" if node is not None else "equal share of the allowed cpus (a GPU's node unknown)")
     except Exception as e:  # noqa: BLE001
         info["error"] = repr(e)
     return info
+
+
+def host_report():
+    """Where this rank's threads may run: its own mask and how many of its threads have a mask outside it (must be
+    0 after bind_rank_to_numa).  all_gather_object'ed into bench.py's JSON line for N > 1."""
+    own = set(os.sched_getaffinity(0))
+    outside = total = 0
+    try:
+        for t in os.listdir("/proc/self/task"):
+            total += 1
+            try:
+                if not set(os.sched_getaffinity(int(t))) <= own:
+                    outside += 1
+            except OSError:
+                pass
+    except OSError:
+        pass
+    cpus = sorted(own)
+    return {"rank": int(os.environ.get("RANK", "0")), "pid": os.getpid(), "n_cpus": len(cpus), "cpus": cpus,
+            "threads": total, "threads_outside_mask": outside}
+
+
+def gather_objects(obj):
+    """all_gather_object over the job (a list with one entry per rank; [obj] without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
 
 
 def shard_frames(n_frames, rank, world):
@@ -135,15 +271,15 @@ def shard_frames(n_frames, rank, world):
     return range(lo, hi)
 
 
-def frame_stats(frame_id, strings):
-    """One int64 row per frame: (frame, y_bytes, z_bytes, crc32 of y||z)."""
+def frame_stats(frame_id, strings, n_escape=-1):
+    """One int64 row per frame: (frame, y_bytes, z_bytes, crc32 of y||z, escape symbols of the y stream)."""
     y, z = strings[0][0], strings[1][0]
-    return [int(frame_id), len(y), len(z), zlib.crc32(z, zlib.crc32(y)) & 0xFFFFFFFF]
+    return [int(frame_id), len(y), len(z), zlib.crc32(z, zlib.crc32(y)) & 0xFFFFFFFF, int(n_escape)]
 
 
 def gather_stats(rows, device):
     """all_gather of the per-rank stats (padded to the max per-rank frame count; -1 rows are
-    padding).  Returns an int64 tensor [n_frames_total, 4] sorted by frame id on every rank."""
+    padding).  Returns an int64 tensor [n_frames_total, 5] sorted by frame id on every rank."""
     device = _coll_device(device)
     t = torch.tensor(rows, dtype=torch.int64, device=device).reshape(-1, len(STATS_FIELDS))
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

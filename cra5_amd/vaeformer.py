@@ -818,32 +818,44 @@ class VAEformer(nn.Module):
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
         z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
         if self.resolve_on_gpu:
-            y_str = ops.rans_encode_resolved(sr.numpy(), raw.numpy(), esc.numpy())
+            esc_np = esc.numpy()
+            y_str = ops.rans_encode_resolved(sr.numpy(), raw.numpy(), esc_np)
+            n_esc = int(np.count_nonzero(esc_np))
         else:
-            y_str = gc.encode_symbols(y_sym.numpy().reshape(-1), idx.numpy().reshape(-1))
+            sym_np, idx_np = y_sym.numpy().reshape(-1), idx.numpy().reshape(-1)
+            y_str = gc.encode_symbols(sym_np, idx_np)
+            _, ln, off = gc.host_tables()
+            v = sym_np - off[idx_np]
+            n_esc = int(np.count_nonzero((v < 0) | (v >= ln[idx_np] - 2)))
+        # symbols of the y stream coded through the escape path (rans_interface.cpp:120-160): the SURVEY 8(e) stats field
+        self._tls.last_n_escape = n_esc
         return y_str, z_str
 
     @torch.no_grad()
     def compress_from_latent(self, y):
         """vaeformer.py:334-348."""
         self._require_gpu()
-        ystr, zstr = [], []
+        ystr, zstr, nesc = [], [], []
         for b in range(y.shape[0]):
             a, c = self._compress_frame(y=y[b])
             ystr.append(a)
             zstr.append(c)
-        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
+            nesc.append(self._tls.last_n_escape)
+        # ("n_escape": an extra key beside the reference's two - per-frame escape-symbol counts for the stats gather)
+        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz]), "n_escape": nesc}
 
     @torch.no_grad()
     def compress(self, x):
         """vaeformer.py:350-376."""
         self._require_gpu()
-        ystr, zstr = [], []
+        ystr, zstr, nesc = [], [], []
         for b in range(x.shape[0]):
             a, c = self._compress_frame(x=x[b])
             ystr.append(a)
             zstr.append(c)
-        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
+            nesc.append(self._tls.last_n_escape)
+        # ("n_escape": an extra key beside the reference's two - per-frame escape-symbol counts for the stats gather)
+        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz]), "n_escape": nesc}
 
     def _decompress_frame(self, y_string, z_string, shape, reconstruct, mean=None, std=None):
         """host: decode z | GPU: h_s, indexes | host: decode y | GPU: de-quantise (+ g_s)."""

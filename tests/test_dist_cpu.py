@@ -25,7 +25,7 @@ def _worker(rank, world, port, n_frames, q):
     for f in D.shard_frames(n_frames, r, w):
         y = bytes([f % 251]) * (100 + f)       # stand-in streams: the stats only look at bytes
         z = bytes([(f * 7) % 251]) * (10 + f)
-        rows.append(D.frame_stats(f, [[y], [z]]))
+        rows.append(D.frame_stats(f, [[y], [z]], n_escape=3 * f))
     D.barrier()
     stats = D.gather_stats(rows, torch.device("cpu"))
     t = D.max_over_ranks(1.0 + r, torch.device("cpu"))
@@ -56,7 +56,7 @@ def test_two_rank_gloo_allgather():
     import zlib
     for f in range(n_frames):
         y, z = bytes([f % 251]) * (100 + f), bytes([(f * 7) % 251]) * (10 + f)
-        expect.append([f, len(y), len(z), zlib.crc32(z, zlib.crc32(y)) & 0xFFFFFFFF])
+        expect.append([f, len(y), len(z), zlib.crc32(z, zlib.crc32(y)) & 0xFFFFFFFF, 3 * f])
     for r, stats, t in res:
         assert stats == expect      # every rank sees every frame, sorted
         assert t == 2.0             # max over ranks
@@ -66,6 +66,8 @@ def test_single_process_passthrough():
     rows = [D.frame_stats(1, [[b"ab"], [b"c"]]), D.frame_stats(0, [[b"x"], [b""]])]
     s = D.gather_stats(rows, torch.device("cpu"))
     assert s[:, 0].tolist() == [0, 1] and s[1, 1:3].tolist() == [2, 1]
+    assert s.shape[1] == len(D.STATS_FIELDS) == 5 and D.STATS_FIELDS[4] == "n_escape"
+    assert s[:, 4].tolist() == [-1, -1]                                                   # not counted by this caller
 
 
 def test_bench_self_launches_two_ranks_dry():
@@ -87,6 +89,72 @@ def test_bench_self_launches_two_ranks_dry():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["self_launched"] is True and d["backend"] == "gloo"
     assert d["stats_rows"] == 10 and d["frames_of_rank0"] == [0, 5]
+    assert d["stats_fields"] == list(D.STATS_FIELDS)
+
+
+def test_bench_self_launches_eight_ranks_dry():
+    """The driver's `python bench.py --gpus 8` shape: 8 ranks self-launched, each pinned to its
+    own share of the host cores BEFORE its process group exists, 8 x K frames sharded and gathered, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                            "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "1",
+                        "--dry-dist"], cwd=root, env=env, capture_output=True, text=True, timeout=900,
+                       stdin=subprocess.DEVNULL)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["stats_rows"] == 64 and d["frames_of_rank0"] == [0, 8]     # BASELINE configs[3]: 8 per rank
+    hosts = d["host_per_rank"]
+    assert sorted(h["rank"] for h in hosts) == list(range(8))
+    n_allowed = len(os.sched_getaffinity(0))
+    if n_allowed >= 8:
+        # every rank bound, to a set disjoint from every other rank's, and none of its threads outside its mask
+        assert d["host_cpu_sets_disjoint"] is True
+        assert all(h["numa_bind"] and h["numa_bind"]["bound"] for h in hosts)
+        assert sum(h["n_cpus"] for h in hosts) <= n_allowed
+    assert all(h["threads_outside_mask"] == 0 for h in hosts)
+
+
+def test_plan_rank_cpus_one_rule_for_all_ranks():
+    """when the NUMA node of ANY rank's GPU is unknown every rank falls back to the same rule (equal shares of
+    the allowed CPUs) - a node-bound rank and a fallback rank must never overlap."""
+    nodes_cpus = {0: D._parse_cpulist("0-63,128-191"), 1: D._parse_cpulist("64-127,192-255")}
+    known = [0, 0, 0, 0, 1, 1, 1, 1]
+    mixed = [0, 0, None, 0, 1, 1, 1, 1]
+    for nodes in (known, mixed):
+        seen = set()
+        for local in range(8):
+            node, cpus = D.plan_rank_cpus(local, 8, nodes, range(256), lambda n: nodes_cpus[n])
+            assert cpus and not (seen & set(cpus))
+            seen |= set(cpus)
+            assert (node is None) == (None in nodes)
+        assert len(seen) == 256
+
+
+def test_gpu_bdf_lookup_without_hip(tmp_path, monkeypatch):
+    """The GPU's PCI address comes from the KFD topology in sysfs (no HIP call: the bind runs before the runtime
+    starts) and honours HIP_VISIBLE_DEVICES remapping."""
+    root = tmp_path / "nodes"
+    for i, (simd, loc) in enumerate(((0, 0), (0, 0), (1024, 0x0500), (1024, 0x1508), (1024, 0x6500))):
+        (root / str(i)).mkdir(parents=True)
+        (root / str(i) / "properties").write_text(f"cpu_cores_count 64\nsimd_count {simd}\nlocation_id {loc}\ndomain 0\n")
+    bdfs = D.kfd_gpu_bdfs(str(root))
+    assert bdfs == ["0000:05:00.0", "0000:15:01.0", "0000:65:00.0"]
+    pci = tmp_path / "pci"
+    for b, n in zip(bdfs, (0, 0, 1)):
+        (pci / b).mkdir(parents=True)
+        (pci / b / "numa_node").write_text(f"{n}\n")
+    for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert [D.gpu_numa_node(i, bdfs, str(pci)) for i in range(3)] == [0, 0, 1]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert [D.gpu_numa_node(i, bdfs, str(pci)) for i in range(2)] == [1, 0]
+    assert D.gpu_numa_node(2, bdfs, str(pci)) is None          # not visible
 
 
 def test_bench_refuses_world_size_mismatch():
