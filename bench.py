@@ -461,6 +461,7 @@ def main():
                             "per_rank": None if hosts is None else [
                                 {"rank": h["rank"], "n_cpus": h["n_cpus"], "cpu_span": [h["cpus"][0], h["cpus"][-1]] if h["cpus"] else [],
                                  "threads": h["threads"], "threads_outside_mask": h["threads_outside_mask"],
+                                 "outside_names": h.get("outside_names"),
                                  "numa_node": (h.get("numa_bind") or {}).get("numa_node")} for h in hosts],
                             "cpu_sets_disjoint": None if hosts is None else _disjoint([h["cpus"] for h in hosts])}},
         "warmup_settle_frames": settle_frames,

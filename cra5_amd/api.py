@@ -187,21 +187,23 @@ class cra5_api:
         """normalise + g_a + quant_conv for one physical-units frame (fused normalisation)."""
         with torch.no_grad():
             self.net._require_gpu()
-            with self.net._gpu_phase():
-                return self.net._encode_y_frame(frame, mean=self._mean_flat, std=self._std_flat)
+            return self.net._encode_y_guarded(frame, mean=self._mean_flat, std=self._std_flat)
 
     def encode_to_latent(self, time_stamp=None, save_root=None, latent_type='float', data=None):
         """cra5_api.py:53-71."""
         frame = self._frame(time_stamp, data)
         with torch.no_grad():
             probe = self._finite_probe(frame)
-            y = self._encode_y(frame)
+            try:
+                y = self._encode_y(frame)
+            except FloatingPointError:
+                self._require_finite(probe)     # a non-finite INPUT is the caller's ValueError
+                raise
             self._require_finite(probe)
             if latent_type == 'float':
                 return y.unsqueeze(0)
             if latent_type == 'quantized':
-                with self.net._gpu_phase():
-                    s = self.net._latent_side_frame(y)
+                s = self.net._latent_side_guarded(y)
                 return s["y_hat"].reshape(y.shape).unsqueeze(0)
 
     def latent_to_bin(self, y, save_root=None):
@@ -217,13 +219,16 @@ class cra5_api:
         st2 = time.time()
         with torch.no_grad():
             probe = self._finite_probe(frame)
-            y = self._encode_y(frame)
+            try:
+                y = self._encode_y(frame)
+            except FloatingPointError:
+                self._require_finite(probe)     # a non-finite INPUT is the caller's ValueError
+                raise
             self._require_finite(probe)
             if return_format == 'latent':
                 return y.unsqueeze(0)
             if return_format == 'quantized':
-                with self.net._gpu_phase():
-                    s = self.net._latent_side_frame(y)
+                s = self.net._latent_side_guarded(y)
                 return s["y_hat"].reshape(y.shape).unsqueeze(0)
             output = self.net.compress_from_latent(y.unsqueeze(0))
         st3 = time.time()
@@ -347,7 +352,11 @@ class cra5_api:
             with torch.no_grad():
                 x = self._stage_in(arr)
                 probe = self._finite_probe(x)
-                y_str, z_str = self.net._compress_frame(x=x, mean=self._mean_flat, std=self._std_flat)
+                try:
+                    y_str, z_str = self.net._compress_frame(x=x, mean=self._mean_flat, std=self._std_flat)
+                except FloatingPointError:
+                    self._require_finite(probe)     # a non-finite INPUT is the caller's ValueError, as before
+                    raise
                 self._require_finite(probe)
             output = {"strings": [[y_str], [z_str]], "z_shape": torch.Size([self.net.Hz, self.net.Wz])}
             t2 = time.time()
@@ -426,8 +435,7 @@ class cra5_api:
                 x_hat = self.net.decode_latent(y_hat)
             elif return_format in ('de_normalized', 'de_normlized'):
                 # fused de-normalisation in the overlap-add store
-                with self.net._gpu_phase():
-                    x_hat = self.net._decode_frame(y_hat[0], mean=self._mean_flat, std=self._std_flat)
+                x_hat = self.net._decode_guarded(y_hat[0], mean=self._mean_flat, std=self._std_flat)
             else:
                 raise ValueError(f"unknown return_format {return_format!r}")
             if to_host or out is not None:

@@ -72,20 +72,39 @@ constexpr int MAX_WIN_TOKENS = 1152;   // windowed (not whole-grid) launches: L 
 // Balanced schedule of the whole-grid (global) launch (BAL).  A wave owns 32 queries for the whole key loop and the
 // matrix pipe is per SIMD, so the unit of work is a (32-query tile, SIMD) pair: 10 368 tokens x 16 heads = 5184
 // wave-tiles on 1024 SIMDs = 5.06 each.  The plain launch (27 work-groups of 12 waves per head = 432 on 256 CUs) runs
-// two rounds of 3 waves per SIMD = 6 units, the second round on 176 of the 256 CUs.  Here every head gets `groups` =
-// CUs / heads work-group slots; slot c runs its `base` = T / groups wave-tiles in passes of NW (20 = 12 + 8: 3 + 2
-// waves per SIMD), and the `rem` = T - groups * base leftover tiles of a head (4) are cut along the KEYS into `groups`
-// ranges - 4-wave work-groups, one wave per SIMD, 1/16 of the key loop each - whose partial (m, l, O) a small merge
-// kernel combines in fixed order: 5 + 1/16 units instead of 6.
+// two rounds of 3 waves per SIMD = 6 units, the second round on 176 of the 256 CUs.  Here every head owns `groups` =
+// CUs / heads work-group slots on ONE XCD (its K / V stay in that L2), and every work-group has NW = 12 waves - three
+// per SIMD, the occupancy at which a wave-tile step is cheapest (measured per wave-tile: 208 us with 3 waves per SIMD,
+// 249 with 2, 460 with 1):
+//   * `n_full` passes of FULL tiles: slot c of pass p runs wave-tiles (p groups + c) NW .. + NW over the whole key
+//     loop and stores its output (the same arithmetic as the plain launch: bit-identical);
+//   * the remaining R = T - n_full groups NW wave-tiles form ceil(R / NW) tile GROUPS; their group x key-tile steps are
+//     laid end to end and cut into `groups` equal PIECES (round 4; round 3 ran them as an 8-wave pass at 2 waves per
+//     SIMD plus a key-split 4-wave pass).  Slot c walks piece c - at most two SEGMENTS (group, key range) - and stores
+//     un-normalised partials (m, l, O); attention_merge_kernel combines the <= 3 partials of a group in fixed order.
+// 10 368 x 16: 192 full tiles + 11 groups x 324 key tiles / 16 slots = 324 + 222.75 steps per CU instead of 324 + 324
+// at a lower occupancy.
 struct BalArgs {
   int groups;       // work-group slots per head
-  int base;         // full wave-tiles per slot
-  int n_wg_pass;    // heads * groups: work-groups per pass (mode 0) / per leftover chunk (mode 1)
-  int mode;         // 0: the full passes; 1: leftover tiles, keys split `groups` ways -> partials in ws
-  int rem_tile0;    // mode 1: first leftover wave-tile = groups * base
-  int rem;          // mode 1: leftover wave-tiles per head
-  float *ws;        // mode 1: partials [head][rem][groups][32][WS_ROW]
+  int n_full;       // passes of full wave-tiles
+  int n_wg_pass;    // heads * groups: work-groups per pass
+  int rem_tile0;    // first wave-tile of the key-split part = n_full * groups * NW
+  int rem;          // wave-tiles in the key-split part
+  int n_grp;        // tile groups in the key-split part = ceil(rem / NW)
+  int nkt;          // key tiles of the whole loop = L / 32
+  int maxp;         // most pieces overlapping one group
+  float *ws;        // partials [head][group][piece slot][NW][32][WS_ROW]
 };
+// first step of piece c when S steps are cut into G pieces
+__host__ __device__ __forceinline__ long bal_cut(long S, int G, int c) { return S * c / G; }
+// the piece that holds step s
+__host__ __device__ __forceinline__ int bal_piece_of(long S, int G, long s) {
+  int c = (int)(s * G / S);
+  if (c > G - 1) c = G - 1;
+  while (c > 0 && bal_cut(S, G, c) > s) --c;
+  while (c < G - 1 && bal_cut(S, G, c + 1) <= s) ++c;
+  return c;
+}
 constexpr int WS_ROW = 68;   // floats per query of a partial: O[64], m, l, 2 pad (16-byte rows)
 
 template <int NW, bool HI, bool GLOBAL, bool BAL = false>
@@ -113,7 +132,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   __shared__ long long tab[TAB];
 
   const int L = g.wh * g.ww;
-  int head, win, tile0, n_active = NW, j0 = 0, j1 = L / 32, bal_c = 0;
+  // A work-group runs 1 or 2 SEGMENTS = (NW-tile group of queries, key-tile range); only the key-split part of the
+  // balanced schedule has two.  seg_part < 0: the segment covers the whole key loop and stores the output.
+  int head, win, n_seg = 1;
+  int seg_tile0[2] = {0, 0}, seg_nact[2] = {NW, NW}, seg_j0[2] = {0, 0}, seg_j1[2] = {L / 32, L / 32}, seg_part[2] = {-1, -1};
+  int seg_grp[2] = {0, 0};
   if (BAL) {
     // blockIdx order IS the schedule: all work-groups of pass 0 are dispatched before any of pass 1.  Inside a pass
     // the work-groups of a head sit on ONE XCD (blockIdx % 8 selects the XCD: its K / V stay in that L2).
@@ -128,15 +151,26 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       slot = w % bal.groups;
     }
     win = 0;
-    bal_c = slot;
-    if (bal.mode == 0) {
-      tile0 = slot * bal.base + pass * NW;
-      n_active = min(NW, bal.base - pass * NW);
+    if (pass < bal.n_full) {
+      seg_tile0[0] = (pass * bal.groups + slot) * NW;
     } else {
-      tile0 = bal.rem_tile0 + pass * NW;                 // (leftover chunk `pass` of NW tiles)
-      n_active = min(NW, bal.rem - pass * NW);
-      j0 = (int)((long)(L / 32) * slot / bal.groups);
-      j1 = (int)((long)(L / 32) * (slot + 1) / bal.groups);
+      const long S = (long)bal.n_grp * bal.nkt;
+      const long s0 = bal_cut(S, bal.groups, slot), s1 = bal_cut(S, bal.groups, slot + 1);
+      n_seg = 0;
+      for (long s = s0; s < s1;) {
+        const int gq = (int)(s / bal.nkt);
+        const long e = min(s1, (long)(gq + 1) * bal.nkt);
+        if (n_seg < 2) {
+          seg_grp[n_seg] = gq;
+          seg_tile0[n_seg] = bal.rem_tile0 + gq * NW;
+          seg_nact[n_seg] = min(NW, bal.rem - gq * NW);
+          seg_j0[n_seg] = (int)(s - (long)gq * bal.nkt);
+          seg_j1[n_seg] = (int)(e - (long)gq * bal.nkt);
+          seg_part[n_seg] = slot - bal_piece_of(S, bal.groups, (long)gq * bal.nkt);   // index among the group's pieces
+          ++n_seg;
+        }
+        s = e;
+      }
     }
   } else {
     const int pid = xcd_remap(blockIdx.x, gridDim.x);
@@ -144,7 +178,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     const int wh_id = pid / q_tiles;
     head = wh_id % heads;
     win = wh_id / heads;
-    tile0 = qt * NW;
+    seg_tile0[0] = qt * NW;
   }
   const int wr = win / g.nwc, wc = win - wr * g.nwc;
 
@@ -154,8 +188,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // halves offset of this head's q / k / v slice inside a split row (64 d = 2 chunks = 128 halves)
   const long qoff = 2L * hoff, koff = 2L * (C + hoff), voff = 2L * (2 * C + hoff);
 
-  const int tq = (tile0 + wave) * 32 + l31;
-  const int q_tok = (tq < L && wave < n_active) ? token_of(g, wr, wc, tq) : -1;
   if (!GLOBAL) {
     const long long pad_delta = reinterpret_cast<const char *>(pad_row) - reinterpret_cast<const char *>(qkv);
     for (int t = tid; t < L; t += NT) {
@@ -163,9 +195,18 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       tab[t] = (tok >= 0) ? (long long)tok * ldq * 2 : pad_delta;
     }
   }
-  const bool wave_active = __any(q_tok >= 0);
   constexpr bool IDLE_SKIP = !GLOBAL || BAL;
-  if (!__syncthreads_or(wave_active ? 1 : 0)) return;
+  bool tab_ready = GLOBAL;
+#pragma unroll 1
+  for (int seg = 0; seg < n_seg; ++seg) {
+  const int tile0 = seg_tile0[seg], n_active = seg_nact[seg], j0 = seg_j0[seg], j1 = seg_j1[seg];
+  const int tq = (tile0 + wave) * 32 + l31;
+  const int q_tok = (tq < L && wave < n_active) ? token_of(g, wr, wc, tq) : -1;
+  const bool wave_active = __any(q_tok >= 0);
+  // (also publishes the row-offset table of a windowed launch; between two segments every wave is past the last
+  // barrier of the previous key loop, after which nobody reads the K / V buffers any more)
+  if (!__syncthreads_or(wave_active ? 1 : 0)) continue;
+  tab_ready = true;
 
   // ---- Q fragments: B operand of S^T = K.Q^T; step s covers d = 16s + 8h + (0..7) ---------
   half8 qh[4], ql[4];
@@ -474,10 +515,10 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   if (jt < n_loop) key_tile(jt, s_cur, s_alt);
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (BAL && bal.mode == 1) {
+  if (BAL && seg_part[seg] >= 0) {
     // un-normalised partial of this key range: O, running max (log2 domain), sum - merged by attention_merge_kernel
     if (q_tok >= 0) {
-      float *wrow = bal.ws + ((((size_t)head * bal.rem + (tile0 - bal.rem_tile0) + wave) * bal.groups + bal_c) * 32 + l31) * WS_ROW;
+      float *wrow = bal.ws + (((((size_t)head * bal.n_grp + seg_grp[seg]) * bal.maxp + seg_part[seg]) * NW + wave) * 32 + l31) * WS_ROW;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -490,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
         wrow[65] = l_tot;
       }
     }
-    return;
+    continue;
   }
   // Output.  A query's row is split across the two half-waves: lane (q, h) owns d = 32 t + 8 g + 4 h + (0..3) for
   // g = 0..3.  Stored as they are, that is 16 eight-byte stores per lane for the split layout - and a row-per-lane
@@ -544,21 +585,30 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
         }
       }
   }
+  }   // segments
+  (void)tab_ready;
 }
 
-// Merge of the key-split partials of the leftover queries: block = (head, leftover tile), 256 threads = 32 queries x
-// 8 d-groups of 8; split c contributes exp2(m_c - M) (O_c, l_c), summed in split order (fixed association).
+// Merge of the key-split partials: block = (head, group, tile of the group), 256 threads = 32 queries x 8 d-groups of
+// 8; piece p of the group contributes exp2(m_p - M) (O_p, l_p), summed in piece order (fixed association: deterministic).
 __global__ __launch_bounds__(256) void attention_merge_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                               unsigned short *__restrict__ out_s, int Kp_out, int C,
-                                                              int rem, int groups, int rem_tile0) {
-  const int head = blockIdx.x / rem, i = blockIdx.x - head * rem;
+                                                              BalArgs bal, int nw) {
+  const int t = blockIdx.x % nw, hg = blockIdx.x / nw;
+  const int grp = hg % bal.n_grp, head = hg / bal.n_grp;
+  if (grp * nw + t >= bal.rem) return;                        // the last group may be partial
+  const long S = (long)bal.n_grp * bal.nkt;
+  const int c0 = bal_piece_of(S, bal.groups, (long)grp * bal.nkt);
+  const int c1 = bal_piece_of(S, bal.groups, (long)(grp + 1) * bal.nkt - 1);
+  const int np = c1 - c0 + 1;
   const int q = threadIdx.x >> 3, d0 = (threadIdx.x & 7) * 8;
-  const float *base = ws + (((size_t)head * rem + i) * groups * 32 + q) * WS_ROW;
+  const size_t pstride = (size_t)nw * 32 * WS_ROW;             // floats between two pieces of a group
+  const float *base = ws + ((((size_t)head * bal.n_grp + grp) * bal.maxp) * nw + t) * 32 * WS_ROW + (size_t)q * WS_ROW;
   float M = -INFINITY;
-  for (int c = 0; c < groups; ++c) M = fmaxf(M, base[(size_t)c * 32 * WS_ROW + 64]);
+  for (int c = 0; c < np; ++c) M = fmaxf(M, base[c * pstride + 64]);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lsum = 0.f;
-  for (int c = 0; c < groups; ++c) {
-    const float *r = base + (size_t)c * 32 * WS_ROW;
+  for (int c = 0; c < np; ++c) {
+    const float *r = base + c * pstride;
     const float a = __builtin_amdgcn_exp2f(r[64] - M);
     lsum = fmaf(r[65], a, lsum);
     const float4 v0 = *reinterpret_cast<const float4 *>(r + d0), v1 = *reinterpret_cast<const float4 *>(r + d0 + 4);
@@ -572,7 +622,7 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float *__res
     acc[7] = fmaf(v1.w, a, acc[7]);
   }
   const float inv = 1.0f / lsum;
-  const int tok = (rem_tile0 + i) * 32 + q, col = head * HD + d0;
+  const int tok = (bal.rem_tile0 + grp * nw + t) * 32 + q, col = head * HD + d0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] *= inv;
   if (out) {
@@ -597,25 +647,32 @@ int cu_count() {
 }
 
 constexpr int NW_GLOBAL = 12;   // 384 queries share each K/V tile (4 / 8 / 12 waves per work-group: 1.59 / 1.56 / 1.52 ms)
-constexpr int NW_REM = 4;       // leftover pass: one wave per SIMD
 
 // geometry of the balanced schedule for L tokens, `heads` heads on this device; false = use the plain launch
 bool balanced_plan(int L, int heads, BalArgs &b) {
   const int P = cu_count(), T = L / 32;
   if (P % heads) return false;
   b.groups = P / heads;
-  b.base = T / b.groups;
-  b.rem = T - b.base * b.groups;
-  b.rem_tile0 = b.groups * b.base;
+  b.n_full = T / (b.groups * NW_GLOBAL);
+  b.rem_tile0 = b.n_full * b.groups * NW_GLOBAL;
+  b.rem = T - b.rem_tile0;
+  b.n_grp = (b.rem + NW_GLOBAL - 1) / NW_GLOBAL;
+  b.nkt = T;
   b.n_wg_pass = heads * b.groups;
-  b.mode = 0;
   b.ws = nullptr;
-  // worth it only when a slot has at least one full pass of wave-tiles, and the key split leaves every range a tile
-  return b.base >= NW_GLOBAL && T >= b.groups;
+  b.maxp = 0;
+  const long S = (long)b.n_grp * b.nkt;
+  for (int g = 0; g < b.n_grp; ++g) {
+    const int np = bal_piece_of(S, b.groups, (long)(g + 1) * b.nkt - 1) - bal_piece_of(S, b.groups, (long)g * b.nkt) + 1;
+    if (np > b.maxp) b.maxp = np;
+  }
+  // worth it only when every slot has at least one full pass of wave-tiles; a piece never spans more than two groups
+  // (n_grp <= groups), and every piece holds at least one step (S >= groups whenever there is a remainder)
+  return b.n_full >= 1 && (b.rem == 0 || (b.n_grp <= b.groups && S >= b.groups));
 }
 
 size_t balanced_ws_bytes(const BalArgs &b, int heads) {
-  return (size_t)heads * b.rem * b.groups * 32 * WS_ROW * sizeof(float);
+  return (size_t)heads * b.n_grp * b.maxp * NW_GLOBAL * 32 * WS_ROW * sizeof(float);
 }
 
 template <bool HI>
@@ -627,21 +684,14 @@ int launch_balanced(const unsigned short *qkv, long ldq, const unsigned short *p
   g.wh = H;
   g.ww = W;
   g.nwc = 1;
-  const int n_pass = (b.base + NW_GLOBAL - 1) / NW_GLOBAL;
+  b.ws = ws;
+  const int n_pass = b.n_full + (b.rem ? 1 : 0);
   hipLaunchKernelGGL((window_attention_split_kernel<NW_GLOBAL, HI, true, true>), dim3(n_pass * b.n_wg_pass),
                      dim3(NW_GLOBAL * 64), 0, st, qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, 0, scale, b);
   int rc = (int)hipGetLastError();
   if (rc || b.rem == 0) return rc;
-  BalArgs r = b;
-  r.mode = 1;
-  r.ws = ws;
-  const int n_chunk = (b.rem + NW_REM - 1) / NW_REM;
-  hipLaunchKernelGGL((window_attention_split_kernel<NW_REM, HI, true, true>), dim3(n_chunk * b.n_wg_pass),
-                     dim3(NW_REM * 64), 0, st, qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, 0, scale, r);
-  rc = (int)hipGetLastError();
-  if (rc) return rc;
-  hipLaunchKernelGGL(attention_merge_kernel, dim3(heads * b.rem), dim3(256), 0, st, ws, out, out_s, Kp_out, C, b.rem,
-                     b.groups, b.rem_tile0);
+  hipLaunchKernelGGL(attention_merge_kernel, dim3(heads * b.n_grp * NW_GLOBAL), dim3(256), 0, st, ws, out, out_s, Kp_out,
+                     C, b, NW_GLOBAL);
   return (int)hipGetLastError();
 }
 
@@ -666,7 +716,8 @@ int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, f
 
 static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split, float *out,
                               uint16_t *out_split, int out_kp, int C, int heads, int H, int W, int wh, int ww,
-                              float scale, int hi_only, void *workspace, size_t workspace_bytes, void *stream) {
+                              float scale, int hi_only, void *workspace, size_t workspace_bytes, void *stream,
+                              bool want_balanced) {
   if (!qkv_split || !pad_row_split || (!out && !out_split) || heads <= 0 || C % heads) return CRA5_ERR_ARG;
   if (C / heads != 64 || qkv_kp != 3 * C) return CRA5_ERR_ARG;  // head slices must be chunk-aligned
   if (wh <= 0 || ww <= 0 || H <= 0 || W <= 0 || (wh * ww) % 32) return CRA5_ERR_ARG;
@@ -681,8 +732,10 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   return launch<NWV, HIV, GLV>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st)
   if (whole) {
     BalArgs b;
-    if (workspace && ((uintptr_t)workspace & 15) == 0 && balanced_plan(L, heads, b) &&
-        workspace_bytes >= balanced_ws_bytes(b, heads)) {
+    // (want_balanced: the _ws entry point was used; a plan with no key-split part needs no workspace at all)
+    if (want_balanced && balanced_plan(L, heads, b) &&
+        (balanced_ws_bytes(b, heads) == 0 ||
+         (workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= balanced_ws_bytes(b, heads)))) {
       float *ws = reinterpret_cast<float *>(workspace);
       if (hi_only)
         return launch_balanced<true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, scale, b, ws, st);
@@ -704,7 +757,7 @@ extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp
                                            float *out, uint16_t *out_split, int out_kp, int C, int heads, int H,
                                            int W, int wh, int ww, float scale, int hi_only, void *stream) {
   return attention_dispatch(qkv_split, qkv_kp, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale,
-                            hi_only, nullptr, 0, stream);
+                            hi_only, nullptr, 0, stream, false);
 }
 
 extern "C" size_t cra5_attention_workspace_bytes(int n_tokens, int heads) {
@@ -718,5 +771,13 @@ extern "C" int cra5_window_attention_split_ws(const uint16_t *qkv_split, int qkv
                                               int W, int wh, int ww, float scale, int hi_only, void *workspace,
                                               size_t workspace_bytes, void *stream) {
   return attention_dispatch(qkv_split, qkv_kp, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale,
-                            hi_only, workspace, workspace_bytes, stream);
+                            hi_only, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int cra5_attention_balanced_plan(int n_tokens, int heads, size_t *workspace_bytes) {
+  BalArgs b;
+  if (workspace_bytes) *workspace_bytes = 0;
+  if (n_tokens <= 0 || heads <= 0 || (n_tokens % 32) || !balanced_plan(n_tokens, heads, b)) return 0;
+  if (workspace_bytes) *workspace_bytes = balanced_ws_bytes(b, heads);
+  return 1;
 }

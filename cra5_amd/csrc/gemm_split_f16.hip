@@ -374,7 +374,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   if (nk > 1) CRA5_STAGE_LOAD(1);
   CRA5_TRACE(1);
 
-  // One k-step (an unroll by two with literal stage indexes measured 1.5-3 % slower: tools/probes/archive).
+  // One k-step (an unroll by two with literal stage indexes measured 1.5-3 % slower: DESIGN.md section 9).
 #define CRA5_K_STEP(KT, CUR)                                                                     \
   {                                                                                              \
     CRA5_FRAG_READ(f1ah, f1al, f1bh, f1bl, lds + (CUR)*STAGE, 1);                                \

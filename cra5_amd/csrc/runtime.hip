@@ -7,6 +7,8 @@
 // whole transfer takes max(host memcpy, PCIe) instead of their sum.  Plain C ABI: raw pointers, sizes, a hipStream_t.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <atomic>
 #include <cstring>
 #include <thread>
@@ -20,6 +22,27 @@ inline void cpu_relax() {
 #if defined(__x86_64__)
   __builtin_ia32_pause();
 #endif
+}
+
+// wait loops: a few pauses, then give the core away (the waiters used to spin for the whole transfer - 7 busy cores per
+// copy, and under an N-rank job's per-rank core share the spinners could starve the thread they wait for)
+struct Backoff {
+  int n = 0;
+  void wait() {
+    if (++n < 64) cpu_relax();
+    else std::this_thread::yield();
+  }
+};
+
+// the team never exceeds the CPUs this process may run on (a rank of an N-rank job is pinned to its NUMA share)
+inline int cap_threads(int n_threads) {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int allowed = CPU_COUNT(&set);
+    if (allowed >= 1 && n_threads > allowed) n_threads = allowed;
+  }
+  return n_threads < 1 ? 1 : n_threads;
 }
 
 struct Slices {
@@ -41,6 +64,7 @@ extern "C" int cra5_copy_h2d_staged(void *dst_dev, const void *src_host, void *p
                                     int n_threads, void *stream) {
   if (!dst_dev || !src_host || !pinned || bytes == 0 || n_threads < 1 || n_threads > 64) return CRA5_ERR_ARG;
   if (chunk_bytes < (1u << 16)) chunk_bytes = 1u << 16;
+  n_threads = cap_threads(n_threads);
   const Slices S{bytes, chunk_bytes, n_threads};
   const size_t nc = S.n_chunks();
   std::vector<std::atomic<int>> done(nc);
@@ -63,13 +87,23 @@ extern "C" int cra5_copy_h2d_staged(void *dst_dev, const void *src_host, void *p
     S.range(c, 0, lo, hi);
     if (hi > lo) std::memcpy(static_cast<char *>(pinned) + lo, static_cast<const char *>(src_host) + lo, hi - lo);
     done[c].fetch_add(1, std::memory_order_release);
-    while (done[c].load(std::memory_order_acquire) < n_threads) cpu_relax();
+    for (Backoff b; done[c].load(std::memory_order_acquire) < n_threads;) b.wait();
     const size_t c0 = c * chunk_bytes, len = (c0 + chunk_bytes <= bytes ? chunk_bytes : bytes - c0);
     if (!rc)
       rc = (int)hipMemcpyAsync(static_cast<char *>(dst_dev) + c0, static_cast<const char *>(pinned) + c0, len,
                                hipMemcpyHostToDevice, st);
   }
   for (auto &th : team) th.join();
+  // Return only when the DMA engine has READ the last chunk out of `pinned` (earlier chunks are done by stream order):
+  // the caller re-uses the same staging buffer for its next frame, and overwriting memory a DMA still reads would
+  // corrupt the frame on the device silently.  Costs the tail of one chunk (~0.5 ms of a ~18 ms copy).
+  if (!rc) {
+    hipEvent_t ev = nullptr;
+    rc = (int)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (!rc) rc = (int)hipEventRecord(ev, st);
+    if (!rc) rc = (int)hipEventSynchronize(ev);
+    if (ev) (void)hipEventDestroy(ev);
+  }
   return rc;   // 0 or the hipError_t, like every device launcher
 }
 
@@ -77,6 +111,7 @@ extern "C" int cra5_copy_d2h_staged(void *dst_host, const void *src_dev, void *p
                                     int n_threads, void *stream) {
   if (!dst_host || !src_dev || !pinned || bytes == 0 || n_threads < 1 || n_threads > 64) return CRA5_ERR_ARG;
   if (chunk_bytes < (1u << 16)) chunk_bytes = 1u << 16;
+  n_threads = cap_threads(n_threads);
   const Slices S{bytes, chunk_bytes, n_threads};
   const size_t nc = S.n_chunks();
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -95,9 +130,9 @@ extern "C" int cra5_copy_d2h_staged(void *dst_host, const void *src_dev, void *p
   std::atomic<int> failed(rc);
   auto work = [&](int t) {
     for (size_t c = 0; c < nc; ++c) {
-      while (!ready[c].load(std::memory_order_acquire)) {
+      for (Backoff b; !ready[c].load(std::memory_order_acquire);) {
         if (failed.load(std::memory_order_relaxed)) return;
-        cpu_relax();
+        b.wait();
       }
       size_t lo, hi;
       S.range(c, t, lo, hi);

@@ -2,12 +2,15 @@
 // row = [chunk 0: 32 hi halves | 32 lo halves][chunk 1: ...]; x = hi + lo, hi = f16(x),
 // lo = f16(x - hi).
 //
-// Range: f16 tops out at 65 504.  A FINITE value is SATURATED there before the split (one v_med3 per
-// element), so an out-of-range activation degrades to +-65 504 instead of hi = inf, lo = -inf ->
-// NaN products.  NON-FINITE values stay non-finite: v_med3 alone would turn NaN into -65 504 and +-inf into
-// +-65 504 (it returns min3 when an operand is NaN), i.e. a blown-up frame into finite garbage that no isfinite()
-// probe downstream can see; `fma(v, 0, med3(v))` adds v * 0 = NaN for NaN / inf and +-0 otherwise (one VALU).
-// Builds with
+// Range: f16 tops out at 65 504.  An element beyond it is NOT clipped (round 4; rounds 1-3 saturated at +-65 504, which
+// kept such a frame finite and wrong - silently): `hi = f16(x)` overflows to +-inf, `lo = f16(x - hi)` to -+inf, and
+// every product that reads the pair is inf - inf = NaN.  The poison reaches the fp32 output of the consuming GEMM /
+// attention row, LayerNorm and the global attention spread it over the frame, and the model's finiteness probe at the
+// end of the GPU phase (cra5_amd/vaeformer.py: _range_guard) re-runs that frame on the exact-f32 engines - or raises in
+// the hyper-prior path, whose engine is pinned on both sides of the codec.  Out-of-range activations can therefore
+// never degrade a frame quietly, and the in-range path carries no range-handling instruction at all (the saturating
+// form cost a v_med3 + a v_fma per element in every producer).  In-range values split exactly as before (bit-identical
+// streams).  NaN / inf inputs stay non-finite by the same arithmetic.  Builds with
 // -DCRA5_RANGE_CHECK (python -m cra5_amd.build --flavour rangecheck) additionally count, per
 // producer call site, the elements with |x| >= 65 504 and the non-finite ones
 // (cra5_debug_range_counts in the C ABI): the evidence that a checkpoint's activations stay
@@ -41,16 +44,10 @@ __device__ __forceinline__ void cra5_range_probe(float) {}
 #define CRA5_RANGE_TU(name)
 #endif
 
-// saturate finite values to the f16 range, keep NaN / inf non-finite (NaN)
-__device__ __forceinline__ float cra5_sat(float v) {
-  return __builtin_fmaf(v, 0.0f, __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f));
-}
-
 __device__ __forceinline__ void cra5_split(float v, _Float16 &hi, _Float16 &lo) {
   cra5_range_probe(v);
-  const float vc = cra5_sat(v);
-  hi = (_Float16)vc;
-  lo = (_Float16)(vc - (float)hi);
+  hi = (_Float16)v;                 // |v| >= 65 520: +-inf
+  lo = (_Float16)(v - (float)hi);   // then -+inf (NaN for a non-finite v): the pair poisons every product it enters
 }
 
 // Two values -> packed (hi, hi) and (lo, lo) f16 pairs.  lo = x - f32(hi) is ONE v_fma_mix_f32 reading the f16 half
@@ -62,7 +59,7 @@ __device__ __forceinline__ void cra5_split_pair(float a, float b, unsigned &hi2,
   typedef _Float16 half2v __attribute__((ext_vector_type(2)));
   cra5_range_probe(a);
   cra5_range_probe(b);
-  const float ac = cra5_sat(a), bc = cra5_sat(b);
+  const float ac = a, bc = b;
   const half2v h2 = {(_Float16)ac, (_Float16)bc};
   hi2 = __builtin_bit_cast(unsigned, h2);
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -35,6 +35,8 @@ def init_from_env(device_type="cuda", numa_bind=False):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if numa_bind and world > 1:
+        # ROCr re-pins its own helper threads (async-event loop) to ALL cpus unless told to inherit the creator's mask
+        os.environ.setdefault("HSA_OVERRIDE_CPU_AFFINITY_DEBUG", "0")
         LAST_BIND = bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     force = os.environ.get("CRA5_FORCE_DIST") == "1"   # exercise the RCCL path with a single rank
     if (world > 1 or force) and not dist.is_initialized():
@@ -238,19 +240,25 @@ def host_report():
     0 after bind_rank_to_numa).  all_gather_object'ed into bench.py's JSON line for N > 1."""
     own = set(os.sched_getaffinity(0))
     outside = total = 0
+    names = {}
     try:
         for t in os.listdir("/proc/self/task"):
             total += 1
             try:
                 if not set(os.sched_getaffinity(int(t))) <= own:
                     outside += 1
+                    try:
+                        nm = open(f"/proc/self/task/{t}/comm").read().strip()
+                    except OSError:
+                        nm = "?"
+                    names[nm] = names.get(nm, 0) + 1
             except OSError:
                 pass
     except OSError:
         pass
     cpus = sorted(own)
     return {"rank": int(os.environ.get("RANK", "0")), "pid": os.getpid(), "n_cpus": len(cpus), "cpus": cpus,
-            "threads": total, "threads_outside_mask": outside}
+            "threads": total, "threads_outside_mask": outside, "outside_names": names}
 
 
 def gather_objects(obj):

@@ -324,9 +324,18 @@ def attention_workspace_bytes(n_tokens, heads):
     return int(lib().cra5_attention_workspace_bytes(int(n_tokens), int(heads)))
 
 
-def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None, hi_only=False, workspace=None):
+def attention_balanced_plan(n_tokens, heads):
+    """(plan exists, workspace bytes it needs - possibly 0) of the balanced whole-grid attention schedule on this device."""
+    nb = ctypes.c_size_t(0)
+    ok = lib().cra5_attention_balanced_plan(int(n_tokens), int(heads), ctypes.byref(nb))
+    return bool(ok), int(nb.value)
+
+
+def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None, hi_only=False, workspace=None,
+                           balanced=None):
     """qkv_s: SplitMat [H*W, 3C]; pad_s: SplitMat [1, 3C] (the split qkv bias).  workspace: a device byte tensor
-    of >= attention_workspace_bytes(H*W, heads) -> the balanced schedule for whole-grid launches."""
+    of >= attention_workspace_bytes(H*W, heads) -> the balanced schedule for whole-grid launches (balanced=True with
+    workspace=None: a plan that needs no workspace)."""
     _devs(qkv_s.data, pad_s.data)
     _dev(out)
     N, C = qkv_s.rows, qkv_s.K // 3
@@ -335,13 +344,15 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
         assert out_split.rows == N and out_split.K == C
     scale = float((C // heads) ** -0.5)
     ev = TIMER.start() if TIMER is not None else None
-    if workspace is not None:
-        assert workspace.is_cuda and workspace.is_contiguous()
+    if workspace is not None or balanced:
+        assert workspace is None or (workspace.is_cuda and workspace.is_contiguous())
         check(lib().cra5_window_attention_split_ws(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
                                                    _p(out_split.data) if out_split is not None else None,
                                                    out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
-                                                   scale, int(bool(hi_only)), ctypes.c_void_p(workspace.data_ptr()),
-                                                   workspace.numel() * workspace.element_size(), _stream()),
+                                                   scale, int(bool(hi_only)),
+                                                   ctypes.c_void_p(workspace.data_ptr()) if workspace is not None else None,
+                                                   workspace.numel() * workspace.element_size() if workspace is not None else 0,
+                                                   _stream()),
               "cra5_window_attention_split_ws")
     else:
         check(lib().cra5_window_attention_split(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),

@@ -292,13 +292,17 @@ class VAEformer(nn.Module):
         # GPU phases of concurrent frames: exclusive (one frame's kernels at a time) or shared
         # (streams overlap: other frames' blocks fill the tail / epilogue gaps of a kernel)
         self.gpu_exclusive = os.environ.get("CRA5_GPU_EXCLUSIVE", "1") != "0"
-        self.attn_mode = os.environ.get("CRA5_ATTN", "split")   # "split" (f16-MFMA, fp32-accurate) | "f32"
+        self._attn_mode = os.environ.get("CRA5_ATTN", "split")   # "split" (f16-MFMA, fp32-accurate) | "f32"
         # whole-grid attention: balanced 12 + 8-wave passes + key-split leftover (csrc/attention_split_f16.hip, BAL);
         # CRA5_ATTN_BALANCED=0 keeps the plain 27-work-groups-per-head launch (A/B runs)
         self.attn_balanced = os.environ.get("CRA5_ATTN_BALANCED", "1") != "0"
-        self.gemm_mode = os.environ.get("CRA5_GEMM", "split")
-        if self.gemm_mode not in ("split", "f32"):
+        self._gemm_mode = os.environ.get("CRA5_GEMM", "split")
+        if self._gemm_mode not in ("split", "f32"):
             raise ValueError("CRA5_GEMM must be 'split' or 'f32'")
+        # range guard (csrc/split.h): frames whose split-f16 activations left the f16 range are re-run on the exact-f32
+        # engines; counted here (encode side, decode side), CRA5_RANGE_GUARD=0 turns the re-run into an error
+        self.range_fallbacks = [0, 0]
+        self.range_guard = os.environ.get("CRA5_RANGE_GUARD", "1") != "0"
         # "fp32" (default): 3-product split, fp32-accurate.  "f16": BASELINE.json configs[4] -
         # g_a / g_s projections and attention use plain f16 operands (1 MFMA per product, fp32
         # accumulate); the hyper-prior / GaussianConditional side stays fp32-accurate so that
@@ -327,6 +331,75 @@ class VAEformer(nn.Module):
         self.light_priority = os.environ.get("CRA5_LIGHT_PRIORITY", "1") != "0"
         self._tls = threading.local()  # per-thread workspaces: one frame pipeline per thread/stream
         self.eval()
+
+
+    # ---- engines: model-wide setting, overridable per thread (the range guard re-runs ONE frame on the exact-f32
+    # engines while the other frame threads of the pipeline keep the split engines) ------------------------------
+    @property
+    def gemm_mode(self):
+        o = getattr(self._tls, "engine_override", None)
+        return o if o is not None else self._gemm_mode
+
+    @gemm_mode.setter
+    def gemm_mode(self, v):
+        if v not in ("split", "f32"):
+            raise ValueError("gemm_mode must be 'split' or 'f32'")
+        self._gemm_mode = v
+
+    @property
+    def attn_mode(self):
+        o = getattr(self._tls, "engine_override", None)
+        return o if o is not None else self._attn_mode
+
+    @attn_mode.setter
+    def attn_mode(self, v):
+        self._attn_mode = v
+
+    @contextlib.contextmanager
+    def _exact_f32_engines(self):
+        prev = getattr(self._tls, "engine_override", None)
+        self._tls.engine_override = "f32"
+        try:
+            yield
+        finally:
+            self._tls.engine_override = prev
+
+    @staticmethod
+    def _finite_flag(*tensors):
+        """Device-side probe, asynchronous: one bool tensor, True when every element of every tensor is finite (a sum
+        is non-finite as soon as one addend is; fp32 sums of O(1e7) bounded activations do not overflow)."""
+        ok = None
+        for t in tensors:
+            f = torch.isfinite(t.sum(dtype=torch.float32))
+            ok = f if ok is None else (ok & f)
+        return ok
+
+    def _range_guard(self, side, run, what):
+        """Run one frame's GPU work `run()` -> (result, finite flag [device bool], hyper flag or None).  A non-finite
+        result means a split-f16 store left the f16 range (csrc/split.h poisons it) or the input itself was non-finite:
+        the frame is re-run on the exact-f32 engines (fp32 operands have no such range).  Still non-finite, or the
+        hyper-prior path (pinned engine: both sides of the codec must run the same kernels) non-finite: an error -
+        never a quietly degraded frame."""
+        res, ok, ok_h = run()
+        if bool(ok) and (ok_h is None or bool(ok_h)):
+            return res
+        if ok_h is not None and bool(ok) and not bool(ok_h):
+            raise FloatingPointError(f"{what}: the hyper-prior path produced non-finite entropy parameters (its engine is "
+                                     "pinned on both sides of the codec, there is no fallback): check the checkpoint")
+        if self.gemm_mode == "f32" or not self.range_guard:
+            raise FloatingPointError(f"{what}: non-finite values on the device (" + (
+                "exact-f32 engines: the input or the weights are non-finite" if self.gemm_mode == "f32" else
+                "CRA5_RANGE_GUARD=0: a split-f16 activation left the f16 range, or the input is non-finite") + ")")
+        import warnings
+        warnings.warn(f"{what}: non-finite values with the split-f16 engines (an activation beyond 65 504, csrc/split.h) - "
+                      "re-running this frame on the exact-f32 engines", RuntimeWarning, stacklevel=3)
+        self.range_fallbacks[side] += 1
+        with self._exact_f32_engines():
+            res, ok, ok_h = run()
+        if not (bool(ok) and (ok_h is None or bool(ok_h))):
+            raise FloatingPointError(f"{what}: non-finite values with the exact-f32 engines too - the input frame (or the "
+                                     "latent handed in) holds NaN / inf, or the checkpoint does")
+        return res
 
     # ---- reference-compatible loading (vaeformer.py:168-185, base.py:69-89) -------------
     @classmethod
@@ -487,11 +560,13 @@ class VAEformer(nn.Module):
             qkv_s = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out_name=f"qkv{D}")
             pad_s = self._derive("pad." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)))
             att = self._sbuf(f"att{D}", N, D, zero=True)
-            ws = None
+            ws, bal = None, False
             if blk.window is None and self.attn_balanced:
-                nb = ops.attention_workspace_bytes(N, blk.heads)     # 0: no balanced schedule for this shape
-                ws = self._buf("attn_ws", (nb,), torch.uint8) if nb else None
-            ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att, workspace=ws,
+                # (g_a / g_s outputs depend on the CU count and this schedule by fp32 rounding - include/cra5_amd.h;
+                # only the hyper-prior path, which never takes this branch, must be bit-stable across the codec's sides)
+                bal, nb = ops.attention_balanced_plan(N, blk.heads)
+                ws = self._buf("attn_ws", (nb,), torch.uint8) if (bal and nb) else None
+            ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att, workspace=ws, balanced=bal,
                                        hi_only=self.precision == "f16" and pre.startswith(("g_a.", "g_s.")))
             self._mm(att, pre + ".attn.proj", blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
             h = self._ln(t_out, blk.norm2, f"h{D}")
@@ -753,20 +828,51 @@ class VAEformer(nn.Module):
         h.copy_(t, non_blocking=True)
         return h
 
+
     # ---- public surface (names / return shapes of the reference) ---------------------------
+    def _encode_y_guarded(self, x, mean=None, std=None):
+        """g_a + quant_conv of one frame under the range guard: x [C, H, W] -> y [L, Hp, Wp]."""
+        def run():
+            with self._gpu_phase():
+                y = self._encode_y_frame(x, mean=mean, std=std)
+                flag = self._to_host("ok1", self._finite_flag(y).reshape(1))
+            return y, flag[0], None
+        return self._range_guard(0, run, "encode")
+
+    def _decode_guarded(self, y_hat, mean=None, std=None):
+        """g_s of one frame under the range guard: y_hat [L, Hp, Wp] -> x_hat [C, H, W]."""
+        D = self.cfg['embed_dim']
+
+        def run():
+            with self._gpu_phase():
+                x_hat = self._decode_frame(y_hat, mean=mean, std=std)
+                flag = self._to_host("ok1", self._finite_flag(self._buf(f"t{D}", (self.Hp * self.Wp, D)),
+                                                              x_hat[:, ::61, ::61]).reshape(1))
+            return x_hat, flag[0], None
+        return self._range_guard(1, run, "decode")
+
+    def _latent_side_guarded(self, y, want_lik=False):
+        """Hyper-prior + entropy parameters of one frame; the hyper-prior engine is pinned: non-finite -> error."""
+        with self._gpu_phase():
+            s = self._latent_side_frame(y, want_lik=want_lik)
+            flag = self._to_host("ok_h", self._finite_flag(s["means"], s["scales"]).reshape(1))
+        if not bool(flag[0]):
+            raise FloatingPointError("the hyper-prior path produced non-finite entropy parameters (pinned engine, no "
+                                     "fallback): the latent handed in is non-finite, or the checkpoint is broken")
+        return s
+
     @torch.no_grad()
     def encode_latent(self, x, type='quantized'):
         """vaeformer.py:272-292 -> (y, y_hat, y_likelihoods)."""
         self._require_gpu()
         ys, yh, yl = [], [], []
-        with self._gpu_phase():
-            for b in range(x.shape[0]):
-                y = self._encode_y_frame(x[b])
-                ys.append(y)
-                if type == "quantized":
-                    s = self._latent_side_frame(y, want_lik=True)
-                    yh.append(s["y_hat"].reshape(y.shape))
-                    yl.append(s["y_lik"].reshape(y.shape))
+        for b in range(x.shape[0]):
+            y = self._encode_y_guarded(x[b])
+            ys.append(y)
+            if type == "quantized":
+                s = self._latent_side_guarded(y, want_lik=True)
+                yh.append(s["y_hat"].reshape(y.shape))
+                yl.append(s["y_lik"].reshape(y.shape))
         y = torch.stack(ys)
         if type == "quantized":
             return y, torch.stack(yh), torch.stack(yl)
@@ -776,22 +882,20 @@ class VAEformer(nn.Module):
     def decode_latent(self, y, type='quantized'):
         """vaeformer.py:294-300."""
         self._require_gpu()
-        with self._gpu_phase():
-            return torch.stack([self._decode_frame(y[b]) for b in range(y.shape[0])])
+        return torch.stack([self._decode_guarded(y[b]) for b in range(y.shape[0])])
 
     @torch.no_grad()
     def forward(self, x):
         """vaeformer.py:302-333."""
         self._require_gpu()
         xh, yl, zl, ys = [], [], [], []
-        with self._gpu_phase():
-            for b in range(x.shape[0]):
-                y = self._encode_y_frame(x[b])
-                s = self._latent_side_frame(y, want_lik=True)
-                xh.append(self._decode_frame(s["y_hat"].reshape(y.shape)))
-                yl.append(s["y_lik"].reshape(y.shape))
-                zl.append(s["z_lik"].reshape(-1, self.Hz, self.Wz))
-                ys.append(y)
+        for b in range(x.shape[0]):
+            y = self._encode_y_guarded(x[b])
+            s = self._latent_side_guarded(y, want_lik=True)
+            xh.append(self._decode_guarded(s["y_hat"].reshape(y.shape)))
+            yl.append(s["y_lik"].reshape(y.shape))
+            zl.append(s["z_lik"].reshape(-1, self.Hz, self.Wz))
+            ys.append(y)
         return {"x_hat": torch.stack(xh), "likelihoods": {"y": torch.stack(yl), "z": torch.stack(zl)},
                 "posterior": _Posterior(torch.stack(ys))}
 
@@ -800,21 +904,30 @@ class VAEformer(nn.Module):
         host phase (two rANS streams).  Either x [C,H,W] or y [L,Hp,Wp]."""
         self.entropy_bottleneck._check()
         self.gaussian_conditional._check()
-        with self._gpu_phase(prio=0):
-            if y is None:
-                y = self._encode_y_frame(x, mean=mean, std=std)
-            s = self._latent_side_frame(y.contiguous())
-            z_sym = self._to_host("z_sym", s["z_sym"])
-            gc = self.gaussian_conditional
-            if self.resolve_on_gpu:
-                # symbol -> (start, range, escape payload) against the CDF tables on the device
-                # (SURVEY 8f-2): the host coder below is a pure state-update loop
-                sr, raw, esc = ops.rans_resolve_symbols(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
-                                                        gc._quantized_cdf, gc._cdf_length, gc._offset)
-                sr, raw, esc = self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc)
-            else:
-                y_sym = self._to_host("y_sym", s["y_sym"])
-                idx = self._to_host("idx", s["idx"])
+        gc = self.gaussian_conditional
+
+        def gpu_side():
+            with self._gpu_phase(prio=0):
+                yy = y if y is not None else self._encode_y_frame(x, mean=mean, std=std)
+                s = self._latent_side_frame(yy.contiguous())
+                ok = self._finite_flag(yy)
+                ok_h = self._finite_flag(s["means"], s["scales"])
+                z_sym = self._to_host("z_sym", s["z_sym"])
+                if self.resolve_on_gpu:
+                    # symbol -> (start, range, escape payload) against the CDF tables on the device
+                    # (SURVEY 8f-2): the host coder below is a pure state-update loop
+                    sr, raw, esc = ops.rans_resolve_symbols(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
+                                                            gc._quantized_cdf, gc._cdf_length, gc._offset)
+                    host = (self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
+                else:
+                    host = (self._to_host("y_sym", s["y_sym"]), self._to_host("idx", s["idx"]))
+                flags = self._to_host("ok2", torch.stack([ok, ok_h]))
+            return (z_sym, host), flags[0], flags[1]      # (the phase ended with a stream sync: the flags are on the host)
+        z_sym, host = self._range_guard(0, gpu_side, "compress")
+        if self.resolve_on_gpu:
+            sr, raw, esc = host
+        else:
+            y_sym, idx = host
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
         z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
         if self.resolve_on_gpu:
@@ -875,14 +988,28 @@ class VAEformer(nn.Module):
                                            sym_in=torch.zeros_like(means, dtype=torch.int32), want=("idx",),
                                            scale_bound=self._scale_bound())["idx"]
             idx_h = self._to_host("idx", idx)
+            ok_h = self._to_host("ok_h", self._finite_flag(scales, means).reshape(1))
+        if not bool(ok_h[0]):
+            raise FloatingPointError("decompress: the hyper-prior path produced non-finite entropy parameters (pinned "
+                                     "engine, no fallback): the stream does not belong to this checkpoint, or the "
+                                     "checkpoint is broken")
         y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
         gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
-        with self._gpu_phase(prio=2):
-            y_sym = y_host.to(self.device, non_blocking=True)
-            y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym, want=("y_hat",))["y_hat"]
-            if not reconstruct:
-                return y_hat
-            return self._decode_frame(y_hat, mean=mean, std=std)
+
+        def gpu_side():
+            with self._gpu_phase(prio=2):
+                y_sym = y_host.to(self.device, non_blocking=True)
+                y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym, want=("y_hat",))["y_hat"]
+                if not reconstruct:
+                    return y_hat, torch.ones((), dtype=torch.bool), None
+                x_hat = self._decode_frame(y_hat, mean=mean, std=std)
+                # the residual stream after the last block carries every upstream poison (token-wise, and the global
+                # attention spreads it); the strided image sample covers the un-embed GEMM's own rows
+                flag = self._to_host("ok1", self._finite_flag(self._buf(f"t{self.cfg['embed_dim']}",
+                                                                        (self.Hp * self.Wp, self.cfg['embed_dim'])),
+                                                              x_hat[:, ::61, ::61]).reshape(1))
+            return x_hat, flag[0], None
+        return self._range_guard(1, gpu_side, "decompress")
 
     @torch.no_grad()
     def decompress(self, strings, shape, return_format='reconstructed'):

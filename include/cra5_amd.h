@@ -177,12 +177,19 @@ int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uin
                                 int H, int W, int wh, int ww, float scale, int hi_only,
                                 void *stream);
 
-/* The same call with a caller-owned device workspace (>= cra5_attention_workspace_bytes(H*W, heads) bytes, 16-byte
- * aligned; 0 bytes = this shape has no balanced schedule).  With it, the whole-grid (global) launch runs the BALANCED
- * schedule: every head gets CUs / heads work-group slots, a slot's query tiles run in passes of 12 + 8 waves (3 + 2
- * per SIMD), and the few leftover query tiles are cut along the keys into per-slot ranges whose partial softmaxes a
- * merge kernel combines in fixed order - 5.06 instead of 6 wave-tiles per SIMD on 256 CUs (vit_nlc.py:94-112).
- * Without a workspace, for windowed shapes and where the plan does not apply it is cra5_window_attention_split. */
+/* The same call with a caller-owned device workspace.  With it, the whole-grid (global) launch runs the BALANCED
+ * schedule (vit_nlc.py:94-112): every head owns CUs / heads work-group slots of 12 waves (3 per SIMD); a slot first runs
+ * full passes of 12 query tiles over the whole key loop, then the remaining query tiles - grouped by 12 - are laid end to
+ * end with their key loops and cut into one equal piece per slot, whose un-normalised partial softmaxes a merge kernel
+ * combines in fixed order (deterministic): 324 + 222.75 key steps per CU instead of 2 x 324 on 256 CUs at 10 368 tokens
+ * x 16 heads.  cra5_attention_balanced_plan: 1 when a plan exists for (n_tokens, heads) on the current device - the
+ * bytes it needs go to *workspace_bytes (0 is possible: a plan without a key-split part; `workspace` may then be NULL) -
+ * 0 when the shape has no balanced schedule (the call is then cra5_window_attention_split).  The plan depends on the
+ * device's CU count, and tokens of the key-split part differ from the plain launch by fp32 rounding (same accuracy
+ * class): outputs of g_a / g_s are reproducible per device and schedule, not across them - only the hyper-prior path
+ * (its own kernels) has to be bit-stable between encoder and decoder.  cra5_attention_workspace_bytes: the bytes alone
+ * (0 also when no plan exists - kept for callers that only size a buffer). */
+int cra5_attention_balanced_plan(int n_tokens, int heads, size_t *workspace_bytes);
 size_t cra5_attention_workspace_bytes(int n_tokens, int heads);
 int cra5_window_attention_split_ws(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
                                    float *out, uint16_t *out_split, int out_kp, int C, int heads,
@@ -293,8 +300,9 @@ int cra5_event_destroy(void *ev);
 /* Host <-> device frame copies through a caller-owned PINNED staging buffer of >= `bytes` (csrc/runtime.hip): the copy
  * is cut into `chunk_bytes` chunks; `n_threads` host threads (the caller is one of them) memcpy chunk c + 1 between
  * pageable and pinned memory while the DMA engine moves chunk c on `stream`.  Replaces the `.to(device)` / `.cpu()` of
- * a 1.11 GB frame in cra5_api.py:81-125,153-192.  h2d: returns once every chunk has been handed to the stream (the
- * device copy completes in stream order; `pinned` must stay untouched until then); d2h: returns when `dst_host` holds
+ * a 1.11 GB frame in cra5_api.py:81-125,153-192.  h2d: returns once the DMA engine has read the last chunk out
+ * of `pinned` (the staging buffer and `dst_dev` are the caller's again: the next frame may re-use both); the team is
+ * capped at the CPUs the process may run on and its wait loops yield; d2h: returns when `dst_host` holds
  * all bytes (the copies are queued behind whatever `stream` already holds). */
 int cra5_copy_h2d_staged(void *dst_dev, const void *src_host, void *pinned, size_t bytes, size_t chunk_bytes,
                          int n_threads, void *stream);

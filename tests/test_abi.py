@@ -58,7 +58,7 @@ def test_no_cuda_shims_or_dual_paths_in_sources():
 def test_release_sources_carry_no_experiment_switches():
     """the production translation units once carried ~30 experiment macros (GEMM_PF, GEMM_SKIP_*,
     ATT_SKIP_*, ...), several of which build a kernel that is wrong by design - one stray -D away from shipping.
-    The losers now live under tools/probes/archive/.  Every preprocessor conditional left in cra5_amd/csrc must
+    The losers are in the history (git show fa7b4dd:tools/probes/archive/).  Every preprocessor conditional left in cra5_amd/csrc must
     test one of the macros below, and the build recipe must define none of them for the release flavour."""
     import re as _re
     allowed = {"__HIP_DEVICE_COMPILE__",     # host / device pass of hipcc

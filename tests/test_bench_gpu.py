@@ -30,6 +30,16 @@ def test_bench_json_contract():
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.05 < r["frac"] < 1.0
+    # nothing pre-recorded among the live measurements: the committed rocprofv3 figure sits under its own key
+    assert "frac_rocprof" not in r and "rocprof" not in r
+    assert "committed_reference" not in r or "pre-recorded" in r["committed_reference"]["note"]
+    # the determinism check covers the driver's short configurations too: the timed frames re-code warm-up tensors
+    assert d["determinism_check"]["repeated_frames_with_identical_streams_rank0"] >= 1
+    # SURVEY 8(e) stats row incl. the escape count; the reduced-precision sample (configs[4]) beside the headline
+    assert d["stats_fields"] == ["frame", "y_bytes", "z_bytes", "crc32", "n_escape"] and d["escape_symbols_per_frame"] > 0
+    f16 = d["precision_f16"]
+    assert f16["value"] and f16["value"] > 0.9 * d["value"], f16
+    assert 1e-4 < f16["y_rmse_vs_fp32_run"] < 1e-2 and f16["x_hat_rmse_vs_fp32_run_same_y_hat"] < 1e-2, f16
 
 
 @pytest.mark.gpu
@@ -92,3 +102,29 @@ def test_bench_two_ranks_share_the_gpu_frames_and_streams_match_one_rank(tmp_pat
     two, one = json.load(open(s2)), json.load(open(s1))
     assert [r[0] for r in two] == list(range(6))
     assert two == one
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_share_the_gpu_host_side_stays_inside_each_ranks_share():
+    """`CRA5_SHARE_GPU=1 python bench.py --gpus 4` with gloo for the gather (RCCL refuses several
+    ranks on one device): four self-launched ranks, each pinned - before its process group and HIP runtime start - to
+    its own share of the host cores; after the run no thread of a rank (frame threads, rANS pool, HIP / gloo helpers)
+    has a CPU mask outside the rank's share, and the shares are disjoint."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+           "--settle-batches", "0", "--roofline-steps", "1", "--no-cpu-baseline", "--no-api-sample", "--no-f16-sample",
+           "--no-kernel-timer", "--inflight", "3", "--frame-pool", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500, stdin=subprocess.DEVNULL,
+                       env=dict(env, CRA5_SHARE_GPU="1", CRA5_DIST_BACKEND="gloo"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["collectives"]["backend"] == "gloo" and d["value"] > 0
+    host = d["config"]["host"]
+    assert host["frame_threads_total"] == 12 and host["self_launched"] is True
+    ranks = host["per_rank"]
+    assert sorted(r["rank"] for r in ranks) == [0, 1, 2, 3]
+    assert host["cpu_sets_disjoint"] is True
+    assert all(r["threads_outside_mask"] == 0 and r["threads"] >= 4 for r in ranks), ranks
+    assert host["numa_bind_rank0"]["bound"] and host["numa_bind_rank0"]["before_hip_init"] is True

@@ -809,3 +809,87 @@ def test_full268_pipeline_distinct_frames_equal_serial(big, dev):
     finally:
         big.gpu_exclusive, big.gpu_slots = keep
         pipe.close()
+
+
+# --------------------------------------------------------------------------------------
+# range guard: a checkpoint whose activations leave the f16 range must never give a quietly
+# clipped frame - csrc/split.h poisons the out-of-range element, the model re-runs the frame on the exact-f32 engines
+# --------------------------------------------------------------------------------------
+
+
+def _stress_thin(dev, key_mod):
+    """Thin model with synthetic weights + an outlier-channel modification (`key_mod(net)` runs on the host copy)."""
+    net = VAEformer(0, **synth.thin_model_kwargs())
+    synth.load_synthetic(net, seed=7)
+    with torch.no_grad():
+        key_mod(net)
+    return net.to(dev)
+
+
+def test_range_guard_reruns_an_overflowing_encode_on_the_exact_f32_engines(dev):
+    """Massive-activation hidden units in an encoder MLP (four fc1 rows x 3e5: their GELU outputs are ~1e5..1e6, beyond
+    f16's 65 504): the split GELU epilogue poisons them, y comes out non-finite, the guard re-runs the frame on the
+    exact-f32 engines.  The result is the pure exact-f32 run's, bit for bit, and matches the CPU oracle."""
+    def mod(net):
+        net.g_a.blocks[3].mlp.fc1.weight[:4] *= 3e5
+    net = _stress_thin(dev, mod)
+    x = synth.synth_frame(8, seed=2).unsqueeze(0).to(dev)
+    with pytest.warns(RuntimeWarning, match="exact-f32"):
+        out = net.compress(x)
+    assert net.range_fallbacks == [1, 0]
+    rec = net.decompress(out["strings"], out["z_shape"])["x_hat"]      # g_s is untouched: split engines, no fallback
+    assert torch.isfinite(rec).all() and net.range_fallbacks == [1, 0]
+    with pytest.warns(RuntimeWarning):
+        y = net.encode_latent(x, type='float')[0]
+    assert torch.isfinite(y).all()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    y_ref = R.encode_y(x.cpu(), sd, R.cfg_thin())
+    e = rmse(y, y_ref) / max(1.0, float(y_ref.double().pow(2).mean().sqrt()))
+    print(f"range guard: y (exact-f32 re-run) vs CPU oracle: relative rmse {e:.2e}")
+    assert e <= 1e-5
+    # the pure exact-f32 engines give the same streams (the re-run IS that engine)
+    ref_net = _stress_thin(dev, mod)
+    ref_net.gemm_mode, ref_net.attn_mode = "f32", "f32"
+    out_f32 = ref_net.compress(x)
+    assert ref_net.range_fallbacks == [0, 0]
+    assert out_f32["strings"] == out["strings"]
+    # guard off: an error, never a quietly clipped frame
+    net.range_guard = False
+    with pytest.raises(FloatingPointError, match="f16 range"):
+        net.compress(x)
+
+
+def test_range_guard_decode_side_and_pinned_hyper_path(dev):
+    """The same on the decode side (outlier rows in a g_s MLP: decompress() re-runs g_s on the exact-f32 engines and
+    matches the oracle), and in the hyper-prior path, whose engine is pinned on both sides of the codec: an error."""
+    base = VAEformer(0, **synth.thin_model_kwargs())
+    synth.load_synthetic(base, seed=7)
+    base = base.to(dev)
+    x = synth.synth_frame(8, seed=2).unsqueeze(0).to(dev)
+    out = base.compress(x)                                   # a valid stream pair of the unmodified entropy side
+
+    def mod_gs(net):
+        net.g_s.blocks[2].mlp.fc1.weight[:4] *= 3e5
+    net = _stress_thin(dev, mod_gs)
+    with pytest.warns(RuntimeWarning, match="exact-f32"):
+        rec = net.decompress(out["strings"], out["z_shape"])["x_hat"]
+    assert net.range_fallbacks == [0, 1] and torch.isfinite(rec).all()
+    y_hat = net.decompress(out["strings"], out["z_shape"], return_format='latent')
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    x_ref = R.g_s(y_hat.cpu(), sd, R.cfg_thin())
+    e = rmse(rec, x_ref) / max(1.0, float(x_ref.double().pow(2).mean().sqrt()))
+    print(f"range guard: x_hat (exact-f32 re-run) vs CPU oracle: relative rmse {e:.2e}")
+    assert e <= 1e-5
+
+    def mod_hs(net):
+        net.h_s.blocks[1].mlp.fc1.weight[:4] *= 3e5
+    bad = _stress_thin(dev, mod_hs)
+    with pytest.raises(FloatingPointError, match="hyper-prior"):
+        bad.compress(x)
+    with pytest.raises(FloatingPointError, match="hyper-prior"):
+        bad.decompress(out["strings"], out["z_shape"])
+    # a non-finite input frame is not a range event: both engines see it, the error says so
+    xn = x.clone()
+    xn[0, 3, 100, 200] = float("nan")
+    with pytest.warns(RuntimeWarning), pytest.raises(FloatingPointError, match="input frame"):
+        base.compress(xn)

@@ -17,9 +17,9 @@ for name, (wh, ww) in (("global", (72, 144)), ("w24", (24, 24)), ("w12x48", (12,
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"split {name:8s}: {dt*1e3:8.3f} ms  {4.0*H*W*wh*ww*C/dt/1e12:7.1f} TF", flush=True)
 
-nb = ops.attention_workspace_bytes(H * W, heads)
-if nb:
-    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+ok, nb = ops.attention_balanced_plan(H * W, heads)
+if ok:
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
     for _ in range(2): ops.window_attention_split(qs, ps, heads, H, W, H, W, out_split=out_s, workspace=ws)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): ops.window_attention_split(qs, ps, heads, H, W, H, W, out_split=out_s, workspace=ws)
