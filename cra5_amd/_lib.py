@@ -47,6 +47,10 @@ SIGNATURES = {
                                           c_int, c_int, c_float, c_void_p]),
     "cra5_window_attention_split": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "cra5_unembed_side_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "cra5_gemm_nt_split_unembed": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
+                                           c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p]),
     "cra5_attention_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cra5_attention_balanced_plan": (c_int, [c_int, c_int, P(c_size_t)]),
     "cra5_window_attention_split_ws": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

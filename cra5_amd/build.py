@@ -27,7 +27,8 @@ SOURCES = ["host_entropy.cpp", "gemm_f32.hip", "gemm_split_f16.hip", "attention_
            "elementwise.hip", "hyper.hip", "runtime.hip"]
 SOURCES = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 HEADERS = [os.path.join(ROOT, "include", "cra5_amd.h"), os.path.join(CSRC, "split.h"),
-           os.path.join(CSRC, "gemm_split_epilogue.inc"), os.path.join(CSRC, "gemm_split_epilogue_fast.inc")]
+           os.path.join(CSRC, "gemm_split_epilogue.inc"), os.path.join(CSRC, "gemm_split_epilogue_fast.inc"),
+           os.path.join(CSRC, "gemm_split_epilogue_unembed.inc")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # per-file flags.  gemm_split_f16.hip: the epilogue's row-block loop must unroll FULLY in every instantiation (a

@@ -111,11 +111,19 @@ __device__ unsigned long long g_gemm_trace[5 * 8192];
 #define CRA5_TRACE(slot)
 #endif
 
-template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3>
+// Geometry of the fused un-embed epilogue (UE = true, gemm_split_epilogue_unembed.inc): C is then the reconstruction
+// x[C][H][W] itself.
+struct UnembedArgs {
+  float *side;                 // [C][Hp][2][W]: the ky = 0 / ky = 10 rows, un-normalised (cra5_unembed_fixup adds the pairs)
+  const float *mean, *stdv;    // per channel, or both null (normalised output)
+  int H, W, Hp, Wp;
+};
+
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3, bool UE = false>
 __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM == 3)) ? 2 : 1)) void gemm_nt_split_kernel(
     const unsigned short *__restrict__ A, long lda, const unsigned short *__restrict__ W, long ldw, float *C,
     int ldc, unsigned short *Cs, long ldcs, const float *__restrict__ bias, const float *res, int ldr, int M,
-    int N, int Kp, float wscale_inv, int flags, int tiles_n) {
+    int N, int Kp, float wscale_inv, int flags, int tiles_n, UnembedArgs ue) {
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
   constexpr int NT = WM * WN * 64;
@@ -428,7 +436,9 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     for (int c = 0; c < 4; ++c)
       if (nw + c < N) bv[c] = bias[nw + c];
   }
-  {
+  if constexpr (UE) {
+#include "gemm_split_epilogue_unembed.inc"
+  } else {
     // interior tiles of the four epilogue shapes the model uses take the straight-line body; everything else (edge
     // tiles, unaligned outputs, both outputs at once, long-K master accumulators) the generic one
     const bool interior = !LONGK && m0 + BM <= M && n0 + BN <= N;
@@ -473,15 +483,46 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3>
+template <int WM, int WN, int TM, int TN, bool LONGK, int STAGES = 2, int NPROD = 3, bool UE = false>
 int launch(const unsigned short *A, long lda, const unsigned short *W, long ldw, float *C, int ldc,
            unsigned short *Cs, long ldcs, const float *bias, const float *res, int ldr, int M, int N, int Kp,
-           float wscale_inv, int flags, hipStream_t st) {
+           float wscale_inv, int flags, hipStream_t st, UnembedArgs ue = UnembedArgs{}) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK, STAGES, NPROD>), dim3(tiles_m * tiles_n), dim3(WM * WN * 64), 0,
-                     st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, tiles_n);
+  hipLaunchKernelGGL((gemm_nt_split_kernel<WM, WN, TM, TN, LONGK, STAGES, NPROD, UE>), dim3(tiles_m * tiles_n),
+                     dim3(WM * WN * 64), 0, st, A, lda, W, ldw, C, ldc, Cs, ldcs, bias, res, ldr, M, N, Kp, wscale_inv,
+                     flags, tiles_n, ue);
   return (int)hipGetLastError();
+}
+
+// Overlap rows of the fused un-embed: x[c][10 i] = side[c][i - 1][1] (the ky = 10 row of the patch row above, first -
+// the order of the overlap-add kernel this replaces) + side[c][i][0] (this patch row's ky = 0 row), de-normalised; row 0
+// and row H - 1 have one contribution.  One thread per four pixels of an overlap row.
+__global__ __launch_bounds__(256) void unembed_fixup_kernel(const float *__restrict__ side, const float *__restrict__ mean,
+                                                            const float *__restrict__ stdv, float *__restrict__ x, int C,
+                                                            int H, int W, int Hp) {
+  const int w4 = W / 4;
+  const size_t total = (size_t)C * (Hp + 1) * w4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int p4 = (int)(e % w4);
+    const size_t t = e / w4;
+    const int i = (int)(t % (Hp + 1)), c = (int)(t / (Hp + 1));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool have = false;
+    if (i > 0) {
+      v = *reinterpret_cast<const float4 *>(side + (((size_t)c * Hp + (i - 1)) * 2 + 1) * W + 4 * p4);
+      have = true;
+    }
+    if (i < Hp) {
+      const float4 b = *reinterpret_cast<const float4 *>(side + (((size_t)c * Hp + i) * 2 + 0) * W + 4 * p4);
+      v = have ? make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w) : b;
+    }
+    if (mean) {
+      const float m = mean[c], sd = stdv[c];
+      v = make_float4(v.x * sd + m, v.y * sd + m, v.z * sd + m, v.w * sd + m);
+    }
+    *reinterpret_cast<float4 *>(x + ((size_t)c * H + (size_t)10 * i) * W + 4 * p4) = v;
+  }
 }
 
 }  // namespace
@@ -574,6 +615,48 @@ extern "C" int cra5_split_f16(const float *x, int ldx, uint16_t *out, int rows, 
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out, rows,
                      K, Kp, scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t cra5_unembed_side_bytes(int C, int H, int W, int kh, int kw, int sh, int sw) {
+  if (C <= 0 || kh != 11 || kw != 10 || sh != 10 || sw != 10 || H < kh || W < kw || (H - kh) % sh || (W - kw) % sw) return 0;
+  return (size_t)C * ((H - kh) / sh + 1) * 2 * W * sizeof(float);
+}
+
+extern "C" int cra5_gemm_nt_split_unembed(const uint16_t *A, int lda_kp, const uint16_t *Wt, int ldw_kp, float *x,
+                                          float *side, size_t side_bytes, const float *mean, const float *stdv, int M,
+                                          int Kp, float wscale_inv, int C, int H, int W, int kh, int kw, int sh, int sw,
+                                          int hi_only, void *stream) {
+  const size_t need = cra5_unembed_side_bytes(C, H, W, kh, kw, sh, sw);
+  if (!need) return CRA5_ERR_ARG;                       // other geometries: plain GEMM + cra5_col2im_f32
+  if (!A || !Wt || !x || !side || side_bytes < need || M <= 0 || Kp <= 0 || (Kp % BK) || Kp > 8192) return CRA5_ERR_ARG;
+  if ((mean == nullptr) != (stdv == nullptr)) return CRA5_ERR_ARG;
+  const int Hp = (H - kh) / sh + 1, Wp = (W - kw) / sw + 1, N = C * kh * kw;
+  if (M != Hp * Wp || (W % 4)) return CRA5_ERR_ARG;
+  if (lda_kp < Kp || ldw_kp < Kp || (lda_kp % 32) || (ldw_kp % 32) || lda_kp >= (1 << 21) || ldw_kp >= (1 << 21)) return CRA5_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15) || ((uintptr_t)x & 15) || ((uintptr_t)side & 15)) return CRA5_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  UnembedArgs ue;
+  ue.side = side;
+  ue.mean = mean;
+  ue.stdv = stdv;
+  ue.H = H;
+  ue.W = W;
+  ue.Hp = Hp;
+  ue.Wp = Wp;
+  const long lda = 2L * lda_kp, ldw = 2L * ldw_kp;
+  int rc;
+  if (hi_only)
+    rc = launch<2, 4, 4, 2, false, 2, 1, true>(A, lda, Wt, ldw, x, 0, nullptr, 0, nullptr, nullptr, 0, M, N, Kp, wscale_inv,
+                                               CRA5_GEMM_HI_ONLY, st, ue);
+  else
+    rc = launch<2, 4, 4, 2, false, 2, 3, true>(A, lda, Wt, ldw, x, 0, nullptr, 0, nullptr, nullptr, 0, M, N, Kp, wscale_inv,
+                                               0, st, ue);
+  if (rc) return rc;
+  const size_t total = (size_t)C * (Hp + 1) * (W / 4);
+  size_t g = (total + 255) / 256;
+  if (g > 65535) g = 65535;
+  hipLaunchKernelGGL(unembed_fixup_kernel, dim3((unsigned)g), dim3(256), 0, st, side, mean, stdv, x, C, H, W, Hp);
   return (int)hipGetLastError();
 }
 

@@ -251,7 +251,9 @@ def host_report():
                         nm = open(f"/proc/self/task/{t}/comm").read().strip()
                     except OSError:
                         nm = "?"
+                    m = sorted(os.sched_getaffinity(int(t)))
                     names[nm] = names.get(nm, 0) + 1
+                    names[f"{nm}:mask"] = [len(m), m[0], m[-1]]
             except OSError:
                 pass
     except OSError:

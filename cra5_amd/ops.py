@@ -224,6 +224,30 @@ def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=Non
     return out
 
 
+def unembed_side_bytes(C, H, W, kh, kw, sh, sw):
+    """Bytes of the side buffer of gemm_unembed for this geometry; 0: the fused form does not take it."""
+    return int(lib().cra5_unembed_side_bytes(C, H, W, kh, kw, sh, sw))
+
+
+def gemm_unembed(a, w, C, H, W, kh, kw, sh, sw, side, mean=None, std=None, out=None, hi_only=False):
+    """Fused un-embed (cra5_gemm_nt_split_unembed): a SplitMat [Hp*Wp, K] (tokens), w SplitMat [C*kh*kw, K] -> the image
+    x [C, H, W] (de-normalised when mean / std are given).  `side`: device float buffer of >= unembed_side_bytes()."""
+    _devs(a.data, w.data)
+    _dev(side, mean, std, out)
+    assert a.Kp == w.Kp and a.K == w.K and w.rows == C * kh * kw and a.scale_inv == 1.0
+    if out is None:
+        out = torch.empty((C, H, W), device=a.data.device, dtype=torch.float32)
+    assert out.is_contiguous() and tuple(out.shape) == (C, H, W) and side.is_contiguous()
+    ev = TIMER.start() if TIMER is not None else None
+    check(lib().cra5_gemm_nt_split_unembed(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out), _p(side),
+                                           side.numel() * side.element_size(), _p(mean), _p(std), a.rows, a.Kp,
+                                           float(w.scale_inv), C, H, W, kh, kw, sh, sw, int(bool(hi_only)), _stream()),
+          "cra5_gemm_nt_split_unembed")
+    if ev is not None:
+        TIMER.stop("gemm_nt_split", ev, 2.0 * a.rows * w.rows * a.K)
+    return out
+
+
 def small_gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True,
                         unembed=None):
     """gemm_nt_split for the hyper-prior sizes (csrc/hyper.hip).  unembed = (Hz, Wz, p1, p2): `out` is the

@@ -322,6 +322,9 @@ class VAEformer(nn.Module):
         self.gpu_slots = int(os.environ.get("CRA5_GPU_SLOTS", "3"))
         # y symbols are resolved against the CDF tables by a device kernel (same byte stream)
         self.resolve_on_gpu = os.environ.get("CRA5_RESOLVE_GPU", "1") != "0"
+        # un-embed: GEMM epilogue scatters straight into the reconstruction (csrc/gemm_split_epilogue_unembed.inc);
+        # CRA5_FUSED_UNEMBED=0 keeps the GEMM -> column matrix -> overlap-add pair (A/B runs; bit-identical results)
+        self.fused_unembed = os.environ.get("CRA5_FUSED_UNEMBED", "1") != "0"
         self._gpu_sem = None
         # order of the frames waiting for a GPU-phase slot: "g1" (default) encode-side phases first, "g3" decode-side
         # phases first, "fifo" arrival order (see _SlotGate)
@@ -726,11 +729,20 @@ class VAEformer(nn.Module):
         for j, blk in enumerate(self.g_s.blocks):
             self._block(blk, f"g_s.blocks.{j}", t, t, (self.Hp, self.Wp))
         h = self._ln(t, self.g_s.norm, f"h{D}")
-        ncol = cfg['out_chans'] * kh * kw
+        Cout, (Himg, Wimg) = cfg['out_chans'], cfg['img_size']
+        x_hat = torch.empty((Cout, Himg, Wimg), device=self.device, dtype=torch.float32)
+        nside = ops.unembed_side_bytes(Cout, Himg, Wimg, kh, kw, sh, sw) if self.gemm_mode == "split" else 0
+        if nside and self.fused_unembed and D <= 8192:
+            # ONE fused launch pair: the GEMM epilogue scatters into the reconstruction (de-normalised), the overlap
+            # rows go through a 2-rows-per-patch-row side buffer (no [tokens][C*110] column matrix, no overlap-add pass)
+            side = self._buf("ue_side", (nside // 4,))
+            ops.gemm_unembed(h, self._wsplit("g_s.final", self.g_s.final.weight), Cout, Himg, Wimg, kh, kw, sh, sw, side,
+                             mean=mean, std=std, out=x_hat, hi_only=self.precision == "f16")
+            return x_hat
+        ncol = Cout * kh * kw
         cols = self._buf("ue_cols", (N, ncol))
         self._mm(h, "g_s.final", self.g_s.final.weight, out=cols)
-        x_hat = torch.empty((cfg['out_chans'],) + tuple(cfg['img_size']), device=self.device, dtype=torch.float32)
-        ops.col2im(cols, cfg['out_chans'], kh, kw, sh, sw, self.Hp, self.Wp, mean=mean, std=std, out=x_hat)
+        ops.col2im(cols, Cout, kh, kw, sh, sw, self.Hp, self.Wp, mean=mean, std=std, out=x_hat)
         return x_hat
 
     # ---- latent side: everything between y and the entropy coder ---------------------------
@@ -954,8 +966,8 @@ class VAEformer(nn.Module):
             ystr.append(a)
             zstr.append(c)
             nesc.append(self._tls.last_n_escape)
-        # ("n_escape": an extra key beside the reference's two - per-frame escape-symbol counts for the stats gather)
-        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz]), "n_escape": nesc}
+        self._tls.n_escape = nesc     # (not a dict key: the returned dict has exactly the reference's two)
+        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
 
     @torch.no_grad()
     def compress(self, x):
@@ -967,8 +979,13 @@ class VAEformer(nn.Module):
             ystr.append(a)
             zstr.append(c)
             nesc.append(self._tls.last_n_escape)
-        # ("n_escape": an extra key beside the reference's two - per-frame escape-symbol counts for the stats gather)
-        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz]), "n_escape": nesc}
+        self._tls.n_escape = nesc     # (not a dict key: the returned dict has exactly the reference's two)
+        return {"strings": [ystr, zstr], "z_shape": torch.Size([self.Hz, self.Wz])}
+
+    def last_n_escape(self):
+        """Escape-coded symbols of each y stream the calling thread's last compress() / compress_from_latent() wrote
+        (rans_interface.cpp:120-160): the `n_escape` field of the per-frame stats row."""
+        return list(getattr(self._tls, "n_escape", []))
 
     def _decompress_frame(self, y_string, z_string, shape, reconstruct, mean=None, std=None):
         """host: decode z | GPU: h_s, indexes | host: decode y | GPU: de-quantise (+ g_s)."""

@@ -196,6 +196,21 @@ int cra5_window_attention_split_ws(const uint16_t *qkv_split, int qkv_kp, const 
                                    int H, int W, int wh, int ww, float scale, int hi_only,
                                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* Un-embed as ONE fused launch pair (vit_nlc.py:628-630, 666-669: ConvTranspose2d(D -> C, kernel (11, 10), stride
+ * (10, 10)) on the token grid): x[C][H][W] = overlap-add(A[M = Hp*Wp tokens][K] . W[N = C*110][K]^T) (* std + mean per
+ * channel when both are given - the de-normalisation of cra5_api.py:268-271 fused as in cra5_col2im_f32).  The GEMM's
+ * epilogue stores every accumulator straight into the image (the nine rows of a patch row that have one contribution)
+ * or into `side` (the ky = 0 / ky = 10 rows: [C][Hp][2][W] floats, cra5_unembed_side_bytes), and a small second kernel
+ * adds the overlap pairs in fixed order: no [tokens][C*110] column matrix, no pass over it, deterministic, and
+ * bit-identical to cra5_gemm_nt_split + cra5_col2im_f32.  Only this geometry (kh 11, kw 10, strides 10, W % 4 == 0,
+ * Kp <= 8192); cra5_unembed_side_bytes returns 0 and the launcher CRA5_ERR_ARG for anything else - use the two-call
+ * form then.  hi_only: the reduced-precision mode of cra5_gemm_nt_split. */
+size_t cra5_unembed_side_bytes(int C, int H, int W, int kh, int kw, int sh, int sw);
+int cra5_gemm_nt_split_unembed(const uint16_t *A, int lda_kp, const uint16_t *W_split, int ldw_kp, float *x,
+                               float *side, size_t side_bytes, const float *mean, const float *stdv, int M, int Kp,
+                               float wscale_inv, int C, int H, int W, int kh, int kw, int sh, int sw, int hi_only,
+                               void *stream);
+
 /* ============================ device: layout / conv edges ===================== */
 
 /* Patch gather for a strided Conv2d as GEMM (vit_nlc.py:302-308), fused with the API's

@@ -660,3 +660,52 @@ def test_gemm_model_shapes_all_epilogues(dev, M, N, K):
     assert float((os_.to_float() - o1).abs().max()) <= 2 ** -21 * float(o1.abs().max()) + 2 ** -24
     p2 = ops.gemm_nt_split(sa, sw)
     assert relerr(p2, a.double() @ w.double().t()) < 2e-6
+
+
+@pytest.mark.parametrize("C,K,denorm,hi", [(8, 128, True, False), (8, 128, False, False), (268, 1024, True, False),
+                                            (5, 96, True, True), (159, 1024, True, False)])
+def test_fused_unembed_equals_gemm_plus_overlap_add(dev, C, K, denorm, hi):
+    """cra5_gemm_nt_split_unembed (GEMM epilogue -> reconstruction, overlap rows through the side buffer + fix-up
+    kernel; vit_nlc.py:628-630, 666-669) against the two-call form it replaces - GEMM into the [tokens][C*110] column
+    matrix, then cra5_col2im_f32 - on the model's 72 x 144 token grid: BIT-identical images (same accumulators, same
+    order of the two overlap contributions, same de-normalisation arithmetic), incl. row 0 / row 720 (one contribution),
+    the ragged last tile column (C*110 is not a multiple of 256) and the half-filled last tile row (10 368 = 40.5 x 256)."""
+    H, W, kh, kw, sh, sw = 721, 1440, 11, 10, 10, 10
+    Hp, Wp = 72, 144
+    g = torch.Generator().manual_seed(C * 7 + K)
+    a = ops.split_f16(torch.randn(Hp * Wp, K, generator=g).to(dev))
+    w = ops.split_f16((torch.randn(C * kh * kw, K, generator=g) / np.sqrt(K)).to(dev), "auto")
+    mean = (torch.randn(C, generator=g) * 50).to(dev) if denorm else None
+    std = (torch.rand(C, generator=g) * 30 + 0.5).to(dev) if denorm else None
+    cols = ops.gemm_nt_split(a, w, hi_only=hi)
+    ref = torch.full((C, H, W), float("nan"), device=dev)
+    ops.col2im(cols, C, kh, kw, sh, sw, Hp, Wp, mean=mean, std=std, out=ref)
+    nb = ops.unembed_side_bytes(C, H, W, kh, kw, sh, sw)
+    assert nb == C * Hp * 2 * W * 4
+    side = torch.full((nb // 4,), float("nan"), device=dev)
+    out = torch.full((C, H, W), float("nan"), device=dev)
+    ops.gemm_unembed(a, w, C, H, W, kh, kw, sh, sw, side, mean=mean, std=std, out=out, hi_only=hi)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()                       # every pixel written
+    assert torch.equal(out, ref)
+    # other geometries are refused (the caller keeps the two-call form), never mis-scattered
+    assert ops.unembed_side_bytes(C, H, W, 4, 4, 4, 4) == 0
+    with pytest.raises(Exception):
+        ops.gemm_unembed(a, w, C, H, W, kh, kw, sh, sw, side[: nb // 8], out=out)
+
+
+def test_fused_unembed_in_the_model_equals_the_two_call_form(dev):
+    from cra5_amd.vaeformer import VAEformer
+    net = VAEformer(0, **synth.thin_model_kwargs())
+    synth.load_synthetic(net, seed=7)
+    net = net.to(dev)
+    y_hat = torch.round(2.0 * torch.randn(16, 72, 144, generator=torch.Generator().manual_seed(9))).to(dev)
+    mean, std = torch.linspace(-3, 3, 8, device=dev), torch.linspace(0.5, 4, 8, device=dev)
+    net.fused_unembed = True
+    a = net._decode_frame(y_hat, mean=mean, std=std)
+    b = net._decode_frame(y_hat)
+    net.fused_unembed = False
+    a2 = net._decode_frame(y_hat, mean=mean, std=std)
+    b2 = net._decode_frame(y_hat)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a2) and torch.equal(b, b2)

@@ -830,8 +830,10 @@ def test_range_guard_reruns_an_overflowing_encode_on_the_exact_f32_engines(dev):
     """Massive-activation hidden units in an encoder MLP (four fc1 rows x 3e5: their GELU outputs are ~1e5..1e6, beyond
     f16's 65 504): the split GELU epilogue poisons them, y comes out non-finite, the guard re-runs the frame on the
     exact-f32 engines.  The result is the pure exact-f32 run's, bit for bit, and matches the CPU oracle."""
-    def mod(net):
+    def mod(net):       # fc2 takes the factor back out: the block's output stays O(1), only the hidden units are huge
         net.g_a.blocks[3].mlp.fc1.weight[:4] *= 3e5
+        net.g_a.blocks[3].mlp.fc1.bias[:4] *= 3e5
+        net.g_a.blocks[3].mlp.fc2.weight[:, :4] /= 3e5
     net = _stress_thin(dev, mod)
     x = synth.synth_frame(8, seed=2).unsqueeze(0).to(dev)
     with pytest.warns(RuntimeWarning, match="exact-f32"):
@@ -870,6 +872,8 @@ def test_range_guard_decode_side_and_pinned_hyper_path(dev):
 
     def mod_gs(net):
         net.g_s.blocks[2].mlp.fc1.weight[:4] *= 3e5
+        net.g_s.blocks[2].mlp.fc1.bias[:4] *= 3e5
+        net.g_s.blocks[2].mlp.fc2.weight[:, :4] /= 3e5
     net = _stress_thin(dev, mod_gs)
     with pytest.warns(RuntimeWarning, match="exact-f32"):
         rec = net.decompress(out["strings"], out["z_shape"])["x_hat"]
@@ -883,6 +887,8 @@ def test_range_guard_decode_side_and_pinned_hyper_path(dev):
 
     def mod_hs(net):
         net.h_s.blocks[1].mlp.fc1.weight[:4] *= 3e5
+        net.h_s.blocks[1].mlp.fc1.bias[:4] *= 3e5
+        net.h_s.blocks[1].mlp.fc2.weight[:, :4] /= 3e5
     bad = _stress_thin(dev, mod_hs)
     with pytest.raises(FloatingPointError, match="hyper-prior"):
         bad.compress(x)

@@ -14,6 +14,12 @@ L.cra5_debug_gemm_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 # (name, M, N, K, gelu, res, split_out)
 SHAPES = [("qkv", 10368, 3072, 1024, False, False, True), ("proj", 10368, 1024, 1024, False, True, False),
           ("fc1", 10368, 4096, 1024, True, False, True), ("fc2", 10368, 1024, 4096, False, True, False)]
+if "--active" in sys.argv:
+    # Power / clock experiment: ONE round of 256 x 256 tiles on 64 / 128 / 192 / 256 of the 256 CUs (N = 1024: 4 tile
+    # columns; M = 256 r rows -> 4 r tiles), K = 8192 so that the round lasts ~0.6 ms.  If the chip is power-capped under
+    # the dense MFMA stream, the shader clock falls as more CUs are active and (active CUs x clock) stays constant.
+    os.environ["CRA5_GEMM_TILE"] = "256"
+    SHAPES = [(f"act{4 * r}", 256 * r, 1024, 8192, False, False, False) for r in (8, 16, 32, 48, 64)]
 if "--small" in sys.argv:   # a handful of tiles: prologue / epilogue without 256 CUs bursting together
     SHAPES = [("qkv16", 1024, 3072, 1024, False, False, True), ("fc1_16", 1024, 4096, 1024, True, False, True),
               ("proj8", 1536, 1024, 1024, False, True, False)]
