@@ -509,9 +509,11 @@ def main():
                                "traffic_note": "bytes/launch at the L2<->fabric boundary (Infinity-Cache hits "
                                                "included), newest profiles/r*_traffic.json; algorithmic minimum "
                                                "A + W + C = 55-230 MB/launch",
-                               "peak_note": "dense f16 MFMA peak 2500 TF / %d MFMA(s) per product; a pure MFMA loop on this "
-                                            "chip sustains 1930-1980 TF at the 1.8-1.9 GHz it clocks under that load "
-                                            "(tools/probes/mfma_peak.hip, DESIGN.md section 9)" % nprod,
+                               "peak_note": "dense f16 MFMA peak 2500 TF at the nominal 2.4 GHz / %d MFMA(s) per product.  The chip "
+                                            "does not hold 2.4 GHz under this kernel: one round of 256x256 tiles (K = 8192) runs "
+                                            "at 2.30 GHz on 32 CUs (main loop 791 TF-equivalent per 256 CUs = 95 %% of `peak`) and "
+                                            "at 1.49 GHz on all 256 (502: 60 %%) - profiles/r04_active_cu_sweep.txt; the "
+                                            "sustained all-CU ceiling of this instruction mix is ~0.62 x `peak`" % nprod,
                                "mfma_tflops_issued": nprod * ach, "launches": g["launches"],
                                "avg_launch_ms": g["ms"] / g["launches"], "gemm_ms_per_step": g["ms"] * sample / steps,
                                "launches_sampled_every": sample}

