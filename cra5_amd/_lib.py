@@ -20,6 +20,11 @@ SIGNATURES = {
     "cra5_rans_encode_resolved": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, P(c_void_p), P(c_size_t)]),
     "cra5_rans_decode_with_indexes": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p,
                                               c_void_p, c_void_p]),
+    "cra5_rans_encode_resolved_compact": (c_int, [c_void_p, c_void_p, c_size_t, P(c_void_p), P(c_size_t)]),
+    "cra5_rans_resolve_symbols_compact": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cra5_rans_decode_with_indexes_u8_i16": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int, c_int,
+                                                     c_void_p, c_void_p, c_void_p]),
     "cra5_rans_encode_batch": (c_int, [c_int, P(c_void_p), P(c_void_p), P(c_size_t), P(c_void_p), P(c_int), P(c_int),
                                        P(c_void_p), P(c_void_p), P(c_void_p), P(c_size_t), P(c_int), c_int]),
     "cra5_rans_decode_batch": (c_int, [c_int, P(c_void_p), P(c_size_t), P(c_void_p), P(c_size_t), P(c_void_p), P(c_int),
@@ -47,6 +52,8 @@ SIGNATURES = {
                                           c_int, c_int, c_float, c_void_p]),
     "cra5_window_attention_split": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "cra5_gaussian_conditional_compact_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                                                      c_void_p, c_size_t, c_void_p]),
     "cra5_unembed_side_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "cra5_gemm_nt_split_unembed": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p,
                                            c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -106,9 +113,14 @@ def lib():
 
 
 class Cra5Error(RuntimeError):
-    pass
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
+
+
+ERR_RANGE = -9     # CRA5_ERR_RANGE: a value does not fit the compact record type
 
 
 def check(rc, what):
     if rc != 0:
-        raise Cra5Error(f"{what} failed with status {rc}")
+        raise Cra5Error(f"{what} failed with status {rc}", rc)

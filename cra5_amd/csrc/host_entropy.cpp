@@ -211,11 +211,15 @@ static void build_row_lut(RowLut &l, const int32_t *cdf, int32_t csz) {
   l.built = true;
 }
 
-int decode_symbols(Decoder &d, const int32_t *indexes, size_t n, const Tables &t, int32_t *out) {
+// IdxT / OutT: int32_t / int32_t is the reference's interface; uint8_t / int16_t the compact records of the frame path
+// (a CDF index is < 256, a symbol almost always fits 16 bits: CRA5_ERR_RANGE when one does not - the caller then takes
+// the 32-bit route)
+template <class IdxT, class OutT>
+int decode_symbols(Decoder &d, const IdxT *indexes, size_t n, const Tables &t, OutT *out) {
   constexpr uint64_t mask = (1ull << kProbBits) - 1;
   std::vector<RowLut> luts(static_cast<size_t>(t.n_cdfs > 0 ? t.n_cdfs : 0));
   for (size_t i = 0; i < n; ++i) {
-    const int32_t ci = indexes[i];
+    const int32_t ci = static_cast<int32_t>(indexes[i]);
     if (ci < 0 || ci >= t.n_cdfs || t.sizes[ci] < 2 || t.sizes[ci] > t.stride) return CRA5_ERR_INDEX;
     const int32_t *cdf = t.cdfs + static_cast<size_t>(ci) * t.stride;
     const int32_t csz = t.sizes[ci];
@@ -263,7 +267,9 @@ int decode_symbols(Decoder &d, const int32_t *indexes, size_t n, const Tables &t
       else value += max_value;
     }
     if (!d.ok) return CRA5_ERR_STREAM;
-    out[i] = value + t.offsets[ci];
+    const int32_t sym = value + t.offsets[ci];
+    if (sizeof(OutT) < sizeof(int32_t) && (sym < -32768 || sym > 32767)) return CRA5_ERR_RANGE;
+    out[i] = static_cast<OutT>(sym);
   }
   return CRA5_OK;
 }
@@ -280,8 +286,8 @@ int decoder_init(Decoder &d, const uint8_t *enc, size_t len) {
   return CRA5_OK;
 }
 
-int decode_impl(const uint8_t *enc, size_t len, const int32_t *indexes, size_t n, const Tables &t,
-                int32_t *out) {
+template <class IdxT, class OutT>
+int decode_impl(const uint8_t *enc, size_t len, const IdxT *indexes, size_t n, const Tables &t, OutT *out) {
   if (n && (!indexes || !out)) return CRA5_ERR_ARG;
   Decoder d;
   const int rc = decoder_init(d, enc, len);
@@ -334,6 +340,54 @@ int cra5_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes
   return encode_impl(symbols, indexes, n, Tables{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets}, out, out_len);
 }
 
+int cra5_rans_encode_resolved_compact(const uint32_t *start_range, const uint16_t *rec16, size_t n, uint8_t **out,
+                                      size_t *out_len) {
+  if (!out || !out_len || (n && (!start_range || !rec16))) return CRA5_ERR_ARG;
+  const size_t cap = 10 * n + 2;   // see encode_impl
+  uint32_t *buf = static_cast<uint32_t *>(std::malloc(cap * sizeof(uint32_t)));
+  if (!buf) return CRA5_ERR_ALLOC;
+  Encoder e;
+  e.ptr = buf + cap;
+  for (size_t i = n; i-- > 0;) {
+    const uint32_t sr = start_range[i];
+    const uint32_t rec = rec16[i];
+    if (rec) {
+      if (rec == 0xFFFFu) {   // payload beyond 12 bits / invalid index: the caller uses the 32-bit records
+        std::free(buf);
+        return CRA5_ERR_RANGE;
+      }
+      const int n_nibbles = static_cast<int>(rec >> 12) - 1;
+      const uint32_t r = rec & 0xFFFu;
+      if (n_nibbles < 0 || n_nibbles > 3) {
+        std::free(buf);
+        return CRA5_ERR_INDEX;
+      }
+      for (int j = n_nibbles - 1; j >= 0; --j) e.put_bits((r >> (j * kBypassBits)) & kBypassMax);
+      e.put_bits(static_cast<uint32_t>(n_nibbles));
+    }
+    const uint32_t freq = sr >> 16;
+    if (!freq) {
+      std::free(buf);
+      return CRA5_ERR_INDEX;
+    }
+    e.put(sr & 0xFFFFu, freq);
+  }
+  e.ptr -= 2;  // Rans64EncFlush
+  e.ptr[0] = static_cast<uint32_t>(e.x);
+  e.ptr[1] = static_cast<uint32_t>(e.x >> 32);
+  const size_t nbytes = static_cast<size_t>((buf + cap) - e.ptr) * sizeof(uint32_t);
+  uint8_t *res = static_cast<uint8_t *>(std::malloc(nbytes));
+  if (!res) {
+    std::free(buf);
+    return CRA5_ERR_ALLOC;
+  }
+  std::memcpy(res, e.ptr, nbytes);
+  std::free(buf);
+  *out = res;
+  *out_len = nbytes;
+  return CRA5_OK;
+}
+
 int cra5_rans_encode_resolved(const uint32_t *start_range, const uint32_t *raw, const uint8_t *esc, size_t n,
                               uint8_t **out, size_t *out_len) {
   if (!out || !out_len || (n && (!start_range || !raw || !esc))) return CRA5_ERR_ARG;
@@ -381,6 +435,13 @@ int cra5_rans_encode_resolved(const uint32_t *start_range, const uint32_t *raw, 
 int cra5_rans_decode_with_indexes(const uint8_t *encoded, size_t len, const int32_t *indexes, size_t n,
                                   const int32_t *cdfs, int n_cdfs, int cdf_stride,
                                   const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out) {
+  if (!cdfs || !cdf_sizes || !offsets || n_cdfs <= 0 || cdf_stride < 2) return CRA5_ERR_ARG;
+  return decode_impl(encoded, len, indexes, n, Tables{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets}, out);
+}
+
+int cra5_rans_decode_with_indexes_u8_i16(const uint8_t *encoded, size_t len, const uint8_t *indexes, size_t n,
+                                         const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                         const int32_t *offsets, int16_t *out) {
   if (!cdfs || !cdf_sizes || !offsets || n_cdfs <= 0 || cdf_stride < 2) return CRA5_ERR_ARG;
   return decode_impl(encoded, len, indexes, n, Tables{cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets}, out);
 }

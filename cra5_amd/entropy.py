@@ -108,6 +108,11 @@ class EntropyModel(nn.Module):
         cdf, length, offset = self.host_tables()
         return ops.rans_decode(string, indexes, cdf, length, offset, out=out)
 
+    def decode_symbols_compact(self, string, indexes_u8, out_i16):
+        """The same decoder on the frame path's compact records (uint8 indexes in, int16 symbols out)."""
+        cdf, length, offset = self.host_tables()
+        return ops.rans_decode_compact(string, indexes_u8, cdf, length, offset, out_i16)
+
 
 def eb_pack_params(sd, prefix="entropy_bottleneck"):
     """Per-channel parameter block for the EB likelihood kernel (58 floats/channel, see

@@ -637,6 +637,79 @@ def rans_decode(data, indexes, cdf, cdf_len, offsets, out=None):
     return out
 
 
+def rans_resolve_symbols_compact(symbols, indexes, cdf, cdf_len, offsets):
+    """Device side of the compact resolved encoder -> (start_range int32 [n], rec16 int16 [n], overflow int32 [1])."""
+    for t in (symbols, indexes, cdf, cdf_len, offsets):
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise TypeError("rans_resolve_symbols_compact takes contiguous int32 device tensors")
+    n = symbols.numel()
+    if indexes.numel() != n:
+        raise ValueError("`symbols` and `indexes` should have the same size.")
+    sr = torch.empty(n, device=symbols.device, dtype=torch.int32)
+    rec = torch.empty(n, device=symbols.device, dtype=torch.int16)
+    ovf = torch.empty(1, device=symbols.device, dtype=torch.int32)
+    check(lib().cra5_rans_resolve_symbols_compact(_p(symbols), _p(indexes), n, _p(cdf), cdf.shape[0], cdf.shape[1],
+                                                  _p(cdf_len), _p(offsets), _p(sr), ctypes.c_void_p(rec.data_ptr()),
+                                                  _p(ovf), _stream()), "cra5_rans_resolve_symbols_compact")
+    return sr, rec, ovf
+
+
+def rans_encode_resolved_compact(start_range, rec16):
+    """-> bytes, from HOST arrays: start_range (32-bit words), rec16 (16-bit records)."""
+    s_ = np.ascontiguousarray(start_range).view(np.uint32).reshape(-1)
+    r_ = np.ascontiguousarray(rec16).view(np.uint16).reshape(-1)
+    if s_.size != r_.size:
+        raise ValueError("start_range and rec16 must have the same size")
+    out = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    check(lib().cra5_rans_encode_resolved_compact(s_.ctypes.data, r_.ctypes.data, s_.size, ctypes.byref(out),
+                                                  ctypes.byref(n)), "cra5_rans_encode_resolved_compact")
+    try:
+        return ctypes.string_at(out.value, n.value)
+    finally:
+        lib().cra5_free(out)
+
+
+def rans_decode_compact(data, indexes_u8, cdf, cdf_len, offsets, out):
+    """cra5_rans_decode_with_indexes_u8_i16: uint8 index array -> the int16 numpy array `out` (e.g. the view of a pinned
+    staging tensor).  Raises Cra5Error with status ERR_RANGE when a symbol does not fit int16 (decode again with
+    rans_decode)."""
+    if not (isinstance(indexes_u8, np.ndarray) and indexes_u8.dtype == np.uint8 and indexes_u8.flags.c_contiguous):
+        raise ValueError("`indexes_u8` must be a contiguous uint8 numpy array")
+    if not (isinstance(out, np.ndarray) and out.dtype == np.int16 and out.flags.c_contiguous and out.size == indexes_u8.size):
+        raise ValueError("`out` must be a contiguous int16 numpy array with one entry per index")
+    c, l, o = _np_i32(cdf), _np_i32(cdf_len).reshape(-1), _np_i32(offsets).reshape(-1)
+    buf = (ctypes.c_char * len(data)).from_buffer_copy(data)
+    check(lib().cra5_rans_decode_with_indexes_u8_i16(ctypes.addressof(buf), len(data), indexes_u8.ctypes.data,
+                                                     indexes_u8.size, c.ctypes.data, c.shape[0], c.shape[1],
+                                                     l.ctypes.data, o.ctypes.data, out.ctypes.data),
+          "cra5_rans_decode_with_indexes_u8_i16")
+    return out
+
+
+def gaussian_conditional_compact(scales, means, scale_table=None, sym16_in=None, want_idx8=False, scale_bound=0.11):
+    """Decode-side halves of gaussian_conditional on compact records: want_idx8 -> uint8 CDF indexes (same shape as
+    means); sym16_in (int16 device tensor) -> y_hat = sym + mean (fp32).  Returns {"idx8": ..., "y_hat": ...}."""
+    _dev(scales, means, scale_table, sym16_in)
+    n = means.numel()
+    out = {}
+    idx8 = torch.empty(means.shape, device=means.device, dtype=torch.uint8) if want_idx8 else None
+    y_hat = torch.empty(means.shape, device=means.device, dtype=torch.float32) if sym16_in is not None else None
+    if sym16_in is not None:
+        assert sym16_in.dtype == torch.int16 and sym16_in.is_contiguous() and sym16_in.numel() == n
+    assert means.is_contiguous() and (scales is None or scales.is_contiguous())
+    check(lib().cra5_gaussian_conditional_compact_f32(
+        _p(scales), _p(means), _p(scale_table), scale_table.numel() if scale_table is not None else 0, float(scale_bound),
+        ctypes.c_void_p(sym16_in.data_ptr()) if sym16_in is not None else None,
+        ctypes.c_void_p(idx8.data_ptr()) if idx8 is not None else None, _p(y_hat), n, _stream()),
+          "cra5_gaussian_conditional_compact_f32")
+    if idx8 is not None:
+        out["idx8"] = idx8
+    if y_hat is not None:
+        out["y_hat"] = y_hat
+    return out
+
+
 def pmf_to_quantized_cdf(pmf, precision=16):
     p = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
     out = np.empty(p.size + 1, dtype=np.uint32)

@@ -29,6 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import ERR_RANGE, Cra5Error
 from .entropy import EntropyBottleneck, GaussianConditional, get_scale_table
 
 __all__ = ["VAEformer", "config_for", "block_windows"]
@@ -322,6 +323,9 @@ class VAEformer(nn.Module):
         self.gpu_slots = int(os.environ.get("CRA5_GPU_SLOTS", "3"))
         # y symbols are resolved against the CDF tables by a device kernel (same byte stream)
         self.resolve_on_gpu = os.environ.get("CRA5_RESOLVE_GPU", "1") != "0"
+        # decode side: uint8 CDF indexes / int16 symbols between device and host coder (same streams, same y_hat);
+        # CRA5_COMPACT_RECORDS=0 keeps the int32 records of the reference's interface
+        self.compact_records = os.environ.get("CRA5_COMPACT_RECORDS", "1") != "0"
         # un-embed: GEMM epilogue scatters straight into the reconstruction (csrc/gemm_split_epilogue_unembed.inc);
         # CRA5_FUSED_UNEMBED=0 keeps the GEMM -> column matrix -> overlap-add pair (A/B runs; bit-identical results)
         self.fused_unembed = os.environ.get("CRA5_FUSED_UNEMBED", "1") != "0"
@@ -935,29 +939,42 @@ class VAEformer(nn.Module):
                 pr_y = self._probe(yy)
                 pr_h = self._probe(*self._hs_parent(s["scales"], s["means"]))
                 z_sym = self._to_host("z_sym", s["z_sym"])
-                if self.resolve_on_gpu:
-                    # symbol -> (start, range, escape payload) against the CDF tables on the device
-                    # (SURVEY 8f-2): the host coder below is a pure state-update loop
+                if self.resolve_on_gpu and self.compact_records:
+                    # symbol -> (start | range, 16-bit escape record) against the CDF tables on the device:
+                    # the host coder is a pure state-update loop, and 6 instead of 9 bytes per latent cross PCIe
+                    sr, rec, ovf = ops.rans_resolve_symbols_compact(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
+                                                                    gc._quantized_cdf, gc._cdf_length, gc._offset)
+                    host = ("compact", self._to_host("y_sr", sr), self._to_host("y_rec", rec), self._to_host("y_ovf", ovf))
+                    keep["sym"], keep["idx"] = s["y_sym"], s["idx"]      # for the (rare) 32-bit re-resolve
+                elif self.resolve_on_gpu:
                     sr, raw, esc = ops.rans_resolve_symbols(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
                                                             gc._quantized_cdf, gc._cdf_length, gc._offset)
-                    host = (self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
+                    host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
                 else:
-                    host = (self._to_host("y_sym", s["y_sym"]), self._to_host("idx", s["idx"]))
+                    host = ("plain", self._to_host("y_sym", s["y_sym"]), self._to_host("idx", s["idx"]))
                 fy, fh = self._to_host("ok_y", pr_y), self._to_host("ok_h", pr_h)
             return (z_sym, host), self._finite(fy), self._finite(fh)   # (the phase ended with a stream sync)
+        keep = {}
         z_sym, host = self._range_guard(0, gpu_side, "compress")
-        if self.resolve_on_gpu:
-            sr, raw, esc = host
-        else:
-            y_sym, idx = host
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
         z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
-        if self.resolve_on_gpu:
-            esc_np = esc.numpy()
-            y_str = ops.rans_encode_resolved(sr.numpy(), raw.numpy(), esc_np)
+        if host[0] == "compact" and int(host[3][0]) != 0:
+            # an escape payload beyond 12 bits (|symbol| thousands beyond its table row): this frame takes the 32-bit records
+            with self._gpu_phase(light=True):
+                sr, raw, esc = ops.rans_resolve_symbols(keep["sym"].reshape(-1), keep["idx"].reshape(-1),
+                                                        gc._quantized_cdf, gc._cdf_length, gc._offset)
+                host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
+        keep.clear()
+        if host[0] == "compact":
+            rec_np = host[2].numpy()
+            y_str = ops.rans_encode_resolved_compact(host[1].numpy(), rec_np)
+            n_esc = int(np.count_nonzero(rec_np))
+        elif host[0] == "resolved":
+            esc_np = host[3].numpy()
+            y_str = ops.rans_encode_resolved(host[1].numpy(), host[2].numpy(), esc_np)
             n_esc = int(np.count_nonzero(esc_np))
         else:
-            sym_np, idx_np = y_sym.numpy().reshape(-1), idx.numpy().reshape(-1)
+            sym_np, idx_np = host[1].numpy().reshape(-1), host[2].numpy().reshape(-1)
             y_str = gc.encode_symbols(sym_np, idx_np)
             _, ln, off = gc.host_tables()
             v = sym_np - off[idx_np]
@@ -1011,22 +1028,43 @@ class VAEformer(nn.Module):
             z_hat = ops.entropy_bottleneck(med, None, sym_in=z_sym, want=("z_hat",))["z_hat"]
             scales, means = self._h_s_frame(z_hat)
             scales, means = scales.contiguous(), means.contiguous()
-            idx = ops.gaussian_conditional(scales, means, gc.scale_table,
-                                           sym_in=torch.zeros_like(means, dtype=torch.int32), want=("idx",),
-                                           scale_bound=self._scale_bound())["idx"]
-            idx_h = self._to_host("idx", idx)
+            compact = self.compact_records and gc.scale_table.numel() <= 256
+            if compact:
+                # compact records (round 4): uint8 CDF indexes to the host, int16 symbols back - 8 instead of 21 MB of
+                # PCIe traffic on the decode side's latency path
+                idx = ops.gaussian_conditional_compact(scales, means, gc.scale_table, want_idx8=True,
+                                                       scale_bound=self._scale_bound())["idx8"]
+            else:
+                idx = ops.gaussian_conditional(scales, means, gc.scale_table,
+                                               sym_in=torch.zeros_like(means, dtype=torch.int32), want=("idx",),
+                                               scale_bound=self._scale_bound())["idx"]
+            idx_h = self._to_host("idx8" if compact else "idx", idx)
             ok_h = self._to_host("ok_h", self._probe(*self._hs_parent(scales, means)))
         if not self._finite(ok_h):
             raise FloatingPointError("decompress: the hyper-prior path produced non-finite entropy parameters (pinned "
                                      "engine, no fallback): the stream does not belong to this checkpoint, or the "
                                      "checkpoint is broken")
-        y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
-        gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
+        y_host = None
+        if compact:
+            y_host = self._pinned("y_in16", tuple(means.shape), torch.int16)
+            try:
+                gc.decode_symbols_compact(y_string, idx_h.numpy().reshape(-1), y_host.numpy().reshape(-1))
+            except Cra5Error as e:
+                if e.status != ERR_RANGE:
+                    raise
+                compact = False                      # a symbol beyond int16: the 32-bit records decode the same stream
+                idx_h = idx_h.to(torch.int32)
+        if not compact:
+            y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
+            gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
 
         def gpu_side():
             with self._gpu_phase(prio=2):
                 y_sym = y_host.to(self.device, non_blocking=True)
-                y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym, want=("y_hat",))["y_hat"]
+                if compact:
+                    y_hat = ops.gaussian_conditional_compact(None, means, sym16_in=y_sym)["y_hat"]
+                else:
+                    y_hat = ops.gaussian_conditional(scales, means, gc.scale_table, sym_in=y_sym, want=("y_hat",))["y_hat"]
                 if not reconstruct:
                     return y_hat, True, None
                 x_hat = self._decode_frame(y_hat, mean=mean, std=std)

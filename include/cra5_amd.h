@@ -34,6 +34,7 @@ extern "C" {
 #define CRA5_ERR_STREAM (-6)    /* truncated / corrupt rANS stream                 */
 #define CRA5_ERR_ARG (-7)
 #define CRA5_ERR_UNAVAILABLE (-8) /* entry point not compiled into this build flavour */
+#define CRA5_ERR_RANGE (-9)     /* a value does not fit the compact record type: use the 32-bit entry point */
 
 int cra5_abi_version(void);
 
@@ -57,6 +58,11 @@ int cra5_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes
  * Produces byte-for-byte the stream of cra5_rans_encode_with_indexes. */
 int cra5_rans_encode_resolved(const uint32_t *start_range, const uint32_t *raw, const uint8_t *esc, size_t n,
                               uint8_t **out, size_t *out_len);
+/* The same on COMPACT records (6 instead of 9 bytes per latent between device and host): rec16[i] = 0 for a regular
+ * symbol, (1 + payload nibbles) << 12 | payload for an escape whose payload fits 12 bits; a record 0xFFFF (payload
+ * beyond 12 bits / invalid index) returns CRA5_ERR_RANGE - encode from the 32-bit records then.  Same bytes. */
+int cra5_rans_encode_resolved_compact(const uint32_t *start_range, const uint16_t *rec16, size_t n, uint8_t **out,
+                                      size_t *out_len);
 
 /* RansDecoder.decode_with_indexes (rans_interface.cpp:215-284). `out` has n slots.
  * Unlike the reference (which reads past the end of a corrupt stream) a truncated
@@ -64,6 +70,13 @@ int cra5_rans_encode_resolved(const uint32_t *start_range, const uint32_t *raw, 
 int cra5_rans_decode_with_indexes(const uint8_t *encoded, size_t len, const int32_t *indexes,
                                   size_t n, const int32_t *cdfs, int n_cdfs, int cdf_stride,
                                   const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out);
+
+/* The same decoder on COMPACT records (the frame path's device <-> host traffic: 3 bytes per latent instead of 8):
+ * uint8 CDF indexes (the Gaussian tables have 64 rows), int16 symbols out.  A decoded symbol outside int16 returns
+ * CRA5_ERR_RANGE with `out` partially written: decode again with cra5_rans_decode_with_indexes (same stream). */
+int cra5_rans_decode_with_indexes_u8_i16(const uint8_t *encoded, size_t len, const uint8_t *indexes, size_t n,
+                                         const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                         const int32_t *offsets, int16_t *out);
 
 /* Code `n_streams` independent streams on a pool of `n_threads` host threads
  * (frames are independent units: entropy_models.py:263-272). Arrays of per-stream
@@ -263,6 +276,11 @@ int cra5_gaussian_conditional_f32(const float *y, const int32_t *sym_in, const f
                                   const float *means, const float *scale_table, int n_table,
                                   float scale_bound, float lik_bound, int32_t *idx, int32_t *sym,
                                   float *y_hat, float *lik, size_t n, void *stream);
+/* Decode-side halves of the same op on compact records: idx8 = the CDF index as uint8 (n_table <= 256), or - with
+ * sym16_in - y_hat = sym16_in + mean.  Same arithmetic as cra5_gaussian_conditional_f32 (bit-identical idx / y_hat). */
+int cra5_gaussian_conditional_compact_f32(const float *scales, const float *means, const float *scale_table, int n_table,
+                                          float scale_bound, const int16_t *sym16_in, uint8_t *idx8, float *y_hat,
+                                          size_t n, void *stream);
 
 /* EntropyBottleneck, eval mode (entropy_models.py:434-510, 529-542): z is [C][n_per_ch];
  *   sym = (int)rintf(z - median[c]);  z_hat = sym + median[c]
@@ -283,6 +301,11 @@ int cra5_entropy_bottleneck_f32(const float *z, const int32_t *sym_in, const flo
 int cra5_rans_resolve_symbols_i32(const int32_t *symbols, const int32_t *indexes, size_t n, const int32_t *cdfs,
                                   int n_cdfs, int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets,
                                   uint32_t *start_range, uint32_t *raw, uint8_t *esc, void *stream);
+/* Device side of cra5_rans_encode_resolved_compact; *overflow (device int32) is zeroed on the stream, then set to 1 when
+ * any record is 0xFFFF. */
+int cra5_rans_resolve_symbols_compact(const int32_t *symbols, const int32_t *indexes, size_t n, const int32_t *cdfs,
+                                      int n_cdfs, int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets,
+                                      uint32_t *start_range, uint16_t *rec16, int32_t *overflow, void *stream);
 
 int cra5_gdn_f32(const float *x, const float *beta, const float *gamma, float *y, int B, int C,
                  int HW, int inverse, void *stream);

@@ -899,3 +899,61 @@ def test_range_guard_decode_side_and_pinned_hyper_path(dev):
     xn[0, 3, 100, 200] = float("nan")
     with pytest.warns(RuntimeWarning), pytest.raises(FloatingPointError, match="input frame"):
         base.compress(xn)
+
+
+# --------------------------------------------------------------------------------------
+# compact device <-> host records: same streams, same reconstructions, 32-bit fallback
+# --------------------------------------------------------------------------------------
+
+
+def test_compact_records_device_kernels_match_the_32_bit_ones(thin, thin_side, dev):
+    """resolve_symbols_compact_kernel / gaussian_conditional_compact_kernel against the int32 kernels they shadow, on a
+    real frame's integers."""
+    _, y, s = thin_side
+    gc = thin.gaussian_conditional
+    sym, idx = s["y_sym"].reshape(-1).contiguous(), s["idx"].reshape(-1).contiguous()
+    sr, raw, esc = ops.rans_resolve_symbols(sym, idx, gc._quantized_cdf, gc._cdf_length, gc._offset)
+    sr2, rec, ovf = ops.rans_resolve_symbols_compact(sym, idx, gc._quantized_cdf, gc._cdf_length, gc._offset)
+    torch.cuda.synchronize()
+    assert int(ovf[0]) == 0 and torch.equal(sr, sr2)
+    rec32 = rec.cpu().numpy().view(np.uint16).astype(np.uint32)
+    assert np.array_equal(rec32 >> 12, esc.cpu().numpy().astype(np.uint32))          # 1 + nibble count, 0 for regular symbols
+    assert np.array_equal(rec32 & 0xFFF, raw.cpu().numpy().view(np.uint32))
+    a = ops.rans_encode_resolved(sr.cpu().numpy(), raw.cpu().numpy(), esc.cpu().numpy())
+    assert ops.rans_encode_resolved_compact(sr2.cpu().numpy(), rec.cpu().numpy()) == a
+    sc, mu = s["scales"].contiguous(), s["means"].contiguous()
+    c = ops.gaussian_conditional_compact(sc, mu, gc.scale_table, want_idx8=True, scale_bound=thin._scale_bound())
+    assert torch.equal(c["idx8"].int().reshape(-1), idx)
+    yh = ops.gaussian_conditional_compact(None, mu, sym16_in=s["y_sym"].to(torch.int16).contiguous())["y_hat"]
+    assert torch.equal(yh.reshape(-1), s["y_hat"].reshape(-1))
+
+
+def test_compact_records_same_streams_and_reconstruction_incl_the_32_bit_fallback(thin, thin_side, dev):
+    x, y, s = thin_side
+    assert thin.compact_records
+    out_c = thin.compress(x)
+    rec_c = thin.decompress(out_c["strings"], out_c["z_shape"])["x_hat"]
+    thin.compact_records = False
+    try:
+        out_w = thin.compress(x)
+        rec_w = thin.decompress(out_c["strings"], out_c["z_shape"])["x_hat"]
+    finally:
+        thin.compact_records = True
+    assert out_c["strings"] == out_w["strings"] and torch.equal(rec_c, rec_w)
+    assert thin.last_n_escape()[0] > 0
+    # a latent with symbols far outside every table row (escape payloads beyond 12 bits on the encode side, symbols beyond
+    # int16 on the decode side): both sides fall back to the 32-bit records for that frame, the round trip stays exact
+    y_big = y.clone()
+    y_big[0, 3, 10, 20] += 40000.0          # (inside the f16 range of the h_a input split: no poison, only huge symbols)
+    y_big[0, 5, 11, 21] -= 40000.0
+    out_b = thin.compress_from_latent(y_big)
+    y_hat = thin.decompress(out_b["strings"], out_b["z_shape"], return_format='latent')
+    thin.compact_records = False
+    try:
+        out_b32 = thin.compress_from_latent(y_big)
+        y_hat32 = thin.decompress(out_b["strings"], out_b["z_shape"], return_format='latent')
+    finally:
+        thin.compact_records = True
+    assert out_b["strings"] == out_b32["strings"] and torch.equal(y_hat, y_hat32)
+    assert abs(float(y_hat[0, 3, 10, 20] - y_big[0, 3, 10, 20])) <= 0.5 + 1e-3
+    assert abs(float(y_hat[0, 5, 11, 21] - y_big[0, 5, 11, 21])) <= 0.5 + 1e-3

@@ -354,3 +354,46 @@ def test_host_coder_under_address_and_ub_sanitizers():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_compact_records_write_and_read_the_same_streams(seed):
+    """Round 4: the frame path moves 16-bit escape records / uint8 indexes / int16 symbols between device and host coder
+    (cra5_rans_encode_resolved_compact, cra5_rans_decode_with_indexes_u8_i16).  Same bytes as the 32-bit entry points on
+    the same symbols; values that do not fit return CRA5_ERR_RANGE (the caller re-does that frame with 32-bit records)."""
+    from cra5_amd._lib import ERR_RANGE
+    rng = np.random.default_rng(100 + seed)
+    cdf, lens, offs = _random_tables(rng, 64, 40)
+    n = 20000
+    idx = rng.integers(0, 64, n).astype(np.int32)
+    sym = np.round(rng.standard_normal(n) * 30).astype(np.int32)      # plenty of escapes at both ends, |payload| < 4096
+    ref = ops.rans_encode(sym, idx, cdf, lens, offs)
+    # host restatement of the compact resolve (device kernel: tests/test_kernels_gpu.py)
+    max_v = (lens[idx] - 2).astype(np.int64)
+    v = sym.astype(np.int64) - offs[idx]
+    neg, big = v < 0, v >= max_v
+    raw = np.where(neg, -2 * v - 1, np.where(big, 2 * (v - max_v), 0)).astype(np.uint32)
+    vc = np.where(neg | big, max_v, v)
+    sr = ((cdf[idx, vc].astype(np.uint32) & 0xFFFF) | (((cdf[idx, vc + 1] - cdf[idx, vc]).astype(np.uint32) & 0xFFFF) << 16)).astype(np.uint32)
+    nn = np.zeros(n, np.int64)
+    for k in range(3):
+        nn += (raw >> np.uint32(4 * k)) != 0
+    assert raw.max() < 4096
+    rec = np.where(vc == max_v, ((nn + 1) << 12) | raw, 0).astype(np.uint16)
+    assert ops.rans_encode_resolved_compact(sr, rec) == ref
+    out16 = np.empty(n, np.int16)
+    ops.rans_decode_compact(ref, idx.astype(np.uint8), cdf, lens, offs, out16)
+    assert np.array_equal(out16.astype(np.int32), sym)
+    # a payload beyond 12 bits / a symbol beyond int16: CRA5_ERR_RANGE, never a wrong stream
+    rec_bad = rec.copy()
+    rec_bad[n // 2] = 0xFFFF
+    with pytest.raises(Cra5Error) as ei:
+        ops.rans_encode_resolved_compact(sr, rec_bad)
+    assert ei.value.status == ERR_RANGE
+    sym_big = sym.copy()
+    sym_big[7] = 40000
+    big_stream = ops.rans_encode(sym_big, idx, cdf, lens, offs)
+    with pytest.raises(Cra5Error) as ei:
+        ops.rans_decode_compact(big_stream, idx.astype(np.uint8), cdf, lens, offs, out16)
+    assert ei.value.status == ERR_RANGE
+    assert np.array_equal(ops.rans_decode(big_stream, idx, cdf, lens, offs), sym_big)     # the 32-bit route reads it
