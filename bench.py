@@ -569,6 +569,37 @@ def main():
                     rp, note="pre-recorded profiles/" + rp["file"] + " (rocprofv3 --kernel-trace --stats of the exclusive "
                              "bench command at the commit that added the file; `git log -1 -- profiles/" + rp["file"] +
                              "`); everything else in `roofline` was measured by this run")
+            if net.gemm_mode != "f32" and args.precision == "fp32" and rank == 0:
+                # The same kernel on its best-case shape, measured live: ONE exact round of 256 x 256 tiles (256 tiles on
+                # 256 CUs), K = 8192 - prologue / epilogue amortised over 256 k-steps, no partial round.  What is left
+                # between this figure and `peak` is the clock the chip sustains under the instruction mix (DESIGN.md
+                # section 6.1); what is left between `achieved` and this figure is the model's short-K shapes.
+                try:
+                    g = torch.Generator(device=dev).manual_seed(5)
+                    Mb, Nb, Kb = 256 * (torch.cuda.get_device_properties(dev).multi_processor_count // 8), 2048, 8192
+                    ab = ops.split_f16(torch.randn((Mb, Kb), generator=g, device=dev))
+                    wb = ops.split_f16(torch.randn((Nb, Kb), generator=g, device=dev) * 0.02, "auto")
+                    ob = torch.empty((Mb, Nb), device=dev)
+                    for _ in range(3):
+                        ops.gemm_nt_split(ab, wb, out=ob)
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        ops.gemm_nt_split(ab, wb, out=ob)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    tb = e0.elapsed_time(e1) / 20 * 1e-3
+                    ach_b = 2.0 * Mb * Nb * Kb / tb / 1e12
+                    result["roofline"]["best_case_shape"] = {
+                        "shape_mnk": [Mb, Nb, Kb], "achieved": ach_b, "frac": ach_b / result["roofline"]["peak"],
+                        "launch_ms": tb * 1e3,
+                        "note": "same kernel, one exact round of tiles, K = 8192, 20 back-to-back launches on the current "
+                                "stream (256 x 256 tiles, 8 tile columns x CUs / 8 tile rows); the all-CU sustained clock, not the kernel, sets this "
+                                "figure (profiles/r04_active_cu_sweep.txt)"}
+                    del ab, wb, ob
+                except Exception as ex:  # noqa: BLE001
+                    result["roofline"]["best_case_shape"] = {"achieved": None, "error": repr(ex)}
             result["roofline"]["measured_over"] = (
                 f"a separate un-overlapped pass of {max(1, args.roofline_steps)} frames run right after the timed "
                 "region (HIP events around every launch, on the launch stream, exclusive GPU phases); "
