@@ -281,6 +281,8 @@ def main():
                          "slot i %% pool; with --steps <= pool every frame of the job is distinct)")
     ap.add_argument("--dry-dist", action="store_true",
                     help="no GPU work: launch / rendezvous (gloo) / shard / barrier / all-gather / one JSON line only")
+    ap.add_argument("--no-best-case", action="store_true",
+                    help="skip the live best-case-shape launches of the GEMM kernel (`roofline.best_case_shape`): profiled runs")
     ap.add_argument("--no-f16-sample", action="store_true",
                     help="skip the short reduced-precision sample (`precision_f16`: BASELINE configs[4] on this GPU, rank 0, N = 1)")
     ap.add_argument("--no-api-sample", action="store_true",
@@ -569,7 +571,7 @@ def main():
                     rp, note="pre-recorded profiles/" + rp["file"] + " (rocprofv3 --kernel-trace --stats of the exclusive "
                              "bench command at the commit that added the file; `git log -1 -- profiles/" + rp["file"] +
                              "`); everything else in `roofline` was measured by this run")
-            if net.gemm_mode != "f32" and args.precision == "fp32" and rank == 0:
+            if net.gemm_mode != "f32" and args.precision == "fp32" and rank == 0 and not args.no_best_case:
                 # The same kernel on its best-case shape, measured live: ONE exact round of 256 x 256 tiles (256 tiles on
                 # 256 CUs), K = 8192 - prologue / epilogue amortised over 256 k-steps, no partial round.  What is left
                 # between this figure and `peak` is the clock the chip sustains under the instruction mix (DESIGN.md
