@@ -352,6 +352,10 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
 #define CRA5_PP_READ(ST, KK) CRA5_FRAG_READ(f0ah, f0al, f0bh, f0bl, ST, KK)
 #define CRA5_PP_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
   if (PP) {
+    // A wave group whose rows all lie past M (the lower half of the 41st tile row of the model's 10 368-token launches:
+    // 10 368 = 40.5 x 256) keeps staging and synchronising but issues no MFMAs: its accumulators are never stored, and
+    // under the chip's power limit an MFMA that computes nothing is not free.
+    const bool rows_live = m0 + wm * TM * 32 < M;
     CRA5_STAGE_LOAD(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -359,18 +363,18 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     if (wm == 1) CRA5_PP_BARRIER;   // the second group runs one interval behind
     for (int kt = 0; kt < nk; ++kt) {
       const unsigned short *st = lds + (kt & 1) * STAGE;
-      CRA5_PP_READ(st, 0);
+      if (rows_live) CRA5_PP_READ(st, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) CRA5_STAGE_LOAD((kt + 1) & 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       CRA5_PP_BARRIER;
-      CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
+      if (rows_live) CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
       CRA5_PP_BARRIER;
-      CRA5_PP_READ(st, 1);
+      if (rows_live) CRA5_PP_READ(st, 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (wm == 1) CRA5_PP_DRAIN;
       CRA5_PP_BARRIER;
-      CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
+      if (rows_live) CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
       if (wm == 0) CRA5_PP_DRAIN;
       CRA5_PP_BARRIER;
     }

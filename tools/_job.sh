@@ -1,8 +1,13 @@
 cd $GRAFT_REPO_ROOT
-bash tools/profile_bench.sh r04 > gpurun_out/r04_profile.log 2>&1
-bash tools/pmc_mfma.sh r04 > gpurun_out/r04_mfma.log 2>&1
-cd $GRAFT_REPO_ROOT
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04/r04_bench_unprofiled.json 2> gpurun_out/r04/unprof.err
-python tools/bench_line.py gpurun_out/r04/r04_bench_unprofiled.json
-timeout 300 python -m pytest tests/test_bench_gpu.py -q -k contract 2>&1 | tail -2
-tail -19 gpurun_out/r04_profile.log | cut -c1-200; tail -8 gpurun_out/r04_mfma.log
+mkdir -p gpurun_out/r4l
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -k "gemm or unembed" 2>&1 | tail -3
+for rep in 1 2; do
+  timeout 300 python tools/gemm_bench.py 2>&1 | tail -1
+  CRA5_LIB=build_variants/libcra5_ghead.so timeout 300 python tools/gemm_bench.py 2>&1 | tail -1
+done
+for rep in 1 2 3; do
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case > gpurun_out/r4l/new_$rep.json 2>> gpurun_out/r4l/err.txt
+python tools/bench_line.py gpurun_out/r4l/new_$rep.json
+CRA5_LIB=build_variants/libcra5_ghead.so python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case > gpurun_out/r4l/head_$rep.json 2>> gpurun_out/r4l/err.txt
+python tools/bench_line.py gpurun_out/r4l/head_$rep.json
+done
