@@ -571,7 +571,7 @@ def main():
                     rp, note="pre-recorded profiles/" + rp["file"] + " (rocprofv3 --kernel-trace --stats of the exclusive "
                              "bench command at the commit that added the file; `git log -1 -- profiles/" + rp["file"] +
                              "`); everything else in `roofline` was measured by this run")
-            if net.gemm_mode != "f32" and args.precision == "fp32" and rank == 0 and not args.no_best_case:
+            if net.gemm_mode != "f32" and args.precision == "fp32" and rank == 0 and world == 1 and not args.no_best_case:
                 # The same kernel on its best-case shape, measured live: ONE exact round of 256 x 256 tiles (256 tiles on
                 # 256 CUs), K = 8192 - prologue / epilogue amortised over 256 k-steps, no partial round.  What is left
                 # between this figure and `peak` is the clock the chip sustains under the instruction mix (DESIGN.md
