@@ -944,21 +944,26 @@ class VAEformer(nn.Module):
                     # the host coder is a pure state-update loop, and 6 instead of 9 bytes per latent cross PCIe
                     sr, rec, ovf = ops.rans_resolve_symbols_compact(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
                                                                     gc._quantized_cdf, gc._cdf_length, gc._offset)
-                    host = ("compact", self._to_host("y_sr", sr), self._to_host("y_rec", rec), self._to_host("y_ovf", ovf))
-                    keep["sym"], keep["idx"] = s["y_sym"], s["idx"]      # for the (rare) 32-bit re-resolve
+                    host = ("compact", self._to_host("y_sr", sr), self._to_host("y_rec", rec), None)
+                    keep["sym"], keep["idx"], keep["ovf"] = s["y_sym"], s["idx"], ovf   # for the (rare) 32-bit re-resolve
                 elif self.resolve_on_gpu:
                     sr, raw, esc = ops.rans_resolve_symbols(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
                                                             gc._quantized_cdf, gc._cdf_length, gc._offset)
                     host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
                 else:
                     host = ("plain", self._to_host("y_sym", s["y_sym"]), self._to_host("idx", s["idx"]))
-                fy, fh = self._to_host("ok_y", pr_y), self._to_host("ok_h", pr_h)
-            return (z_sym, host), self._finite(fy), self._finite(fh)   # (the phase ended with a stream sync)
+                # the three tiny results of the phase (finiteness probes of y and of mu / sigma, the compact records'
+                # overflow flag) travel as ONE small copy
+                extra = keep["ovf"].float() if "ovf" in keep else pr_y.new_zeros(1)
+                fl = self._to_host("enc_flags", torch.cat([pr_y, pr_h, extra]))
+            if host[0] == "compact":
+                host = host[:3] + (fl[-1:],)
+            return (z_sym, host), self._finite(fl[:1]), self._finite(fl[1:-1])   # (the phase ended with a stream sync)
         keep = {}
         z_sym, host = self._range_guard(0, gpu_side, "compress")
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
         z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
-        if host[0] == "compact" and int(host[3][0]) != 0:
+        if host[0] == "compact" and float(host[3][0]) != 0.0:
             # an escape payload beyond 12 bits (|symbol| thousands beyond its table row): this frame takes the 32-bit records
             with self._gpu_phase(light=True):
                 sr, raw, esc = ops.rans_resolve_symbols(keep["sym"].reshape(-1), keep["idx"].reshape(-1),
