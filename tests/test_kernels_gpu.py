@@ -709,3 +709,46 @@ def test_fused_unembed_in_the_model_equals_the_two_call_form(dev):
     b2 = net._decode_frame(y_hat)
     torch.cuda.synchronize()
     assert torch.equal(a, a2) and torch.equal(b, b2)
+
+
+def test_global_attention_balanced_schedule_random_shapes(dev):
+    """Randomised plans of the key-split schedule (token counts that leave 0 .. G*12 - 1 remainder tiles, partial last
+    groups, 8 / 16 / 32 heads, n_full = 1 .. 3): against the plain launch - identical on the full-pass tokens, fp32 noise
+    on the key-split ones, every token written."""
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    rng = np.random.default_rng(12)
+    done = 0
+    for _ in range(40):
+        heads = int(rng.choice([8, 16, 32]))
+        if cus % heads:
+            continue
+        tiles = int(rng.integers(12 * (cus // heads), 3 * 12 * (cus // heads) + 40))
+        N, C = tiles * 32, 64 * heads
+        if N * 3 * C * 4 > 1.5e9:
+            continue
+        ok, nb = ops.attention_balanced_plan(N, heads)
+        if not ok:
+            continue
+        full_tiles, n_grp, maxp = _bal_plan(tiles, cus // heads)
+        assert nb == heads * n_grp * maxp * 12 * 32 * 68 * 4
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        qkv = torch.randn(N, 3 * C, generator=g)
+        qkv[:, :2 * C] *= 1.4
+        qs = ops.split_f16(qkv.to(dev))
+        pad = ops.split_f16(torch.zeros(1, 3 * C, device=dev))
+        H, W = 32, tiles
+        plain = ops.window_attention_split(qs, pad, heads, H, W, H, W, out=torch.empty(N, C, device=dev))
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev).fill_(0xFF) if nb else None
+        out = torch.full((N, C), float("nan"), device=dev)
+        ops.window_attention_split(qs, pad, heads, H, W, H, W, out=out, workspace=ws, balanced=True)
+        torch.cuda.synchronize()
+        n_full = full_tiles * 32
+        assert torch.isfinite(out).all(), (tiles, heads)
+        assert torch.equal(out[:n_full], plain[:n_full]), (tiles, heads)
+        if n_full < N:
+            assert rmse(out[n_full:], plain[n_full:]) < 1e-6, (tiles, heads)
+        done += 1
+        del qkv, qs, plain, out, ws
+        if done >= 12:
+            break
+    assert done >= 6

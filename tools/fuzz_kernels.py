@@ -113,7 +113,13 @@ while time.time() < t_end:
             if pad: assert bool((buf[:, N:] == 7.0).all()), ("wrote outside the view", M, N, K)
             if out_s is not None:
                 e2 = rel(out_s.to_float(), ref); assert e2 < 4e-6, ("split out", M, N, K, e2)
-        e = rel(out, ref); worst["gemm"] = max(worst["gemm"], e)
+        e = rel(out, ref)
+        if M * N < 64 and e >= 4e-6:
+            # a handful of outputs: the rmse / rms metric is one number's cancellation luck (seed 3: 1 x 1 x 4096 with
+            # bias + residual cancelling the product).  Judge it against the scale fp32 rounding acts on instead.
+            mag = float((a.double().abs() @ w.double().abs().t()).max()) + 1.0
+            e = float((out.double().cpu() - ref).abs().max()) / mag * 16.0      # < 4e-6 <=> error < 2.5e-7 of sum |terms|
+        worst["gemm"] = max(worst["gemm"], e)
         assert e < 4e-6, ("gemm", M, N, K, bias is not None, res is not None, gelu, int(mode), e)
         n_gemm += 1
     elif kind < 9:
