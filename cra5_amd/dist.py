@@ -97,6 +97,17 @@ def _visible_physical_index(local):
     return idx
 
 
+def visible_gpu_count(n_physical):
+    """Logical GPUs this process sees: every physical one, or the entries of the visibility lists that name one."""
+    n = 0
+    while n < 64:
+        phys = _visible_physical_index(n)
+        if phys is None or phys >= n_physical:
+            break
+        n += 1
+    return n
+
+
 def kfd_gpu_bdfs(root="/sys/class/kfd/kfd/topology/nodes"):
     """PCI addresses of the GPUs in KFD topology order (= ROCr / HIP enumeration order without visibility masks), read
     from sysfs: no HIP call, usable before the runtime is initialised.  [] when the topology is not readable."""
@@ -214,12 +225,7 @@ def bind_rank_to_numa(local, n_local):
     info = {"numa_node": None, "cpus": None, "bound": False}
     try:
         bdfs = kfd_gpu_bdfs()
-        n_vis = 0
-        while _visible_physical_index(n_vis) is not None and _visible_physical_index(n_vis) < len(bdfs) and n_vis < 64:
-            n_vis += 1
-            if not any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")):
-                n_vis = len(bdfs)
-                break
+        n_vis = visible_gpu_count(len(bdfs))
         share = os.environ.get("CRA5_SHARE_GPU") == "1" and n_vis > 0     # tests: ranks share the visible GPUs
         nodes = [gpu_numa_node(i % n_vis if share else i, bdfs) for i in range(n_local)]
         node, cpus = plan_rank_cpus(

@@ -184,3 +184,12 @@ def test_rank_cpu_sets_partition_a_numa_node():
     # unknown topology: equal contiguous shares of what the process may run on
     assert D.rank_cpu_set(1, 2, None, None, range(8), None) == [4, 5, 6, 7]
     assert D._parse_cpulist("0-2,5,7-8\n") == [0, 1, 2, 5, 7, 8]
+
+
+def test_visible_gpu_count(monkeypatch):
+    for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert D.visible_gpu_count(8) == 8 and D.visible_gpu_count(0) == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0,5")
+    assert D.visible_gpu_count(8) == 3
+    assert D.visible_gpu_count(4) == 2          # an entry that names no GPU ends the list, like the runtime's own rule
