@@ -159,6 +159,127 @@ def cpu_baseline(quality, n_threads):
                        f"un-extrapolated figure (`--cpu-baseline full`, one whole frame) is committed under profiles/")}
 
 
+class HwmonSampler:
+    """Board power / sclk from the amdgpu hwmon files, sampled every 20 ms by a host thread (tools/power_probe.py).  On
+    some boxes the files are static (the same values idle or busy): `static` says so and the in-kernel shader clock
+    (ops.ClockSampler) is the attributable figure."""
+
+    def __init__(self):
+        import glob
+        self.dir = None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if any(n.startswith("power1") for n in os.listdir(d)):
+                self.dir = d
+                break
+        self.rows, self.on, self.th = [], False, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except Exception:  # noqa: BLE001
+            return None
+
+    def start(self):
+        if not self.dir:
+            return
+        import threading
+        pf = next((os.path.join(self.dir, n) for n in ("power1_average", "power1_input")
+                   if os.path.exists(os.path.join(self.dir, n))), None)
+        ff = os.path.join(self.dir, "freq1_input")
+        self.on = True
+
+        def run():
+            while self.on:
+                self.rows.append((self._read(pf) if pf else None, self._read(ff)))
+                time.sleep(0.02)
+        self.th = threading.Thread(target=run, daemon=True)
+        self.th.start()
+
+    def stop(self):
+        self.on = False
+        if self.th:
+            self.th.join()
+        if not self.dir:
+            return None
+        pw = [r[0] / 1e6 for r in self.rows if r[0]]
+        fq = [r[1] / 1e6 for r in self.rows if r[1]]
+        cap = self._read(os.path.join(self.dir, "power1_cap"))
+        return {"power_cap_w": cap / 1e6 if cap else None,
+                "power_avg_w": sum(pw) / len(pw) if pw else None, "power_max_w": max(pw) if pw else None,
+                "sclk_hwmon_mhz_mean": sum(fq) / len(fq) if fq else None, "samples": len(self.rows),
+                "static": bool(len(set(pw)) <= 1 and len(set(fq)) <= 1)}
+
+
+def api_pipelined_sample(net, pipe, frames, inflight, n):
+    """PCIe-inclusive throughput of the reference-named API, pipelined (cra5_api.py:81-125,153-192,
+    test.py:14-59): HOST fp32 frames (pageable numpy arrays, physical units) -> `encode_era5_batch` (pinned staging,
+    H2D of one frame under the GPU / rANS phases of the others, .bin files written) -> `decode_batch` (.bin files read,
+    x_hat D2H through pinned buffers, handed to a host consumer that copies it into its own pageable array).  Beside
+    each side, the same side with device-resident frames (no H2D / D2H, no files).  Outside the timed region."""
+    import shutil
+    import tempfile
+    import threading
+    import numpy as np
+    from cra5_amd.api import cra5_api
+    net.gpu_exclusive = False
+    tmp = tempfile.mkdtemp(prefix="cra5_bench_pipe_")
+    try:
+        api = cra5_api(local_root=tmp, device="cuda", weights=net)
+        api._pipe = pipe                                     # the bench's frame threads (their workspaces exist already)
+        n_host = min(8, len(frames))
+        host = [(frames[i][0] * api.std + api.mean).cpu().numpy() for i in range(n_host)]
+        stamps = [f"2024-06-{1 + i // 24:02d}T{i % 24:02d}:00:00" for i in range(n)]
+        data = [host[i % n_host] for i in range(n)]
+        tls = threading.local()
+
+        def consumer(i, arr):                                # a host consumer: the frame leaves the pinned buffer
+            dst = getattr(tls, "dst", None)
+            if dst is None:
+                dst = tls.dst = np.empty(arr.shape, np.float32)
+            np.copyto(dst, arr)
+            return float(dst[0, 0, 0])
+        res = {}
+        for rep in range(2):                                 # rep 0 warms the pinned buffers / page tables
+            nn = n if rep else inflight
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            enc = api.encode_era5_batch(stamps[:nn], data=data[:nn], save_root=tmp + "/CRA5", workers=inflight)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            api.decode_batch(paths=[e["save_path"] for e in enc], workers=inflight, sink=consumer)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            res = {"encode_fps": nn / (t1 - t0), "decode_fps": nn / (t2 - t1), "round_trip_fps": nn / (t2 - t0)}
+        # the same two sides on device-resident frames (what `value` measures, split by side)
+        dev_frames = [frames[i % len(frames)] for i in range(n)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = pipe.map(net.compress, dev_frames)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pipe.map(lambda o: torch.isfinite(net.decompress(o["strings"], o["z_shape"])["x_hat"][0, 0, ::97, ::97]).all(), outs)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        # the batch path writes the file the serial reference-named call writes for the same host array
+        ser = api.encode_era5_as_bin(stamps[0], save_root=tmp + "/SERIAL", data=data[0])
+        same = open(ser["save_path"], "rb").read() == open(enc[0]["save_path"], "rb").read()
+        res.update({
+            "value": res["round_trip_fps"], "unit": "frames/s", "frames": n, "frames_in_flight": inflight,
+            "encode_fps_device_resident": n / (t1 - t0), "decode_fps_device_resident": n / (t2 - t1),
+            "encode_ratio": res["encode_fps"] / (n / (t1 - t0)), "decode_ratio": res["decode_fps"] / (n / (t2 - t1)),
+            "bin_equals_serial_api_call": bool(same),
+            "pcie_bytes_per_frame": {"h2d": int(frames[0].numel() * 4), "d2h": int(frames[0].numel() * 4)},
+            "what": "cra5_api.encode_era5_batch(host fp32 arrays) -> .bin files -> decode_batch(sink=host consumer): pinned "
+                    "double staging per in-flight frame, H2D / D2H of one frame under the other frames' GPU and rANS phases; "
+                    "encode and decode run as two consecutive batch calls, round_trip_fps = n / (t_encode + t_decode) "
+                    "(a device-resident round trip per frame is `value` of the line)"})
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
     torch.distributed.run (one process per GPU; standalone rendezvous on 127.0.0.1, port chosen by the launcher).  stdout / stderr are
@@ -287,6 +408,9 @@ def main():
                     help="skip the short reduced-precision sample (`precision_f16`: BASELINE configs[4] on this GPU, rank 0, N = 1)")
     ap.add_argument("--no-api-sample", action="store_true",
                     help="skip the reference-named single-frame API sample (`api_single_frame`, rank 0, N = 1)")
+    ap.add_argument("--api-frames", type=int, default=36,
+                    help="frames of the pipelined PCIe-inclusive API sample (`api_pipelined`, rank 0, N = 1)")
+    ap.add_argument("--no-clock-sampler", action="store_true", help="no shader-clock sampler wave beside the timed region")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="N > 1: do not pin a rank's threads to its GPU's NUMA node share of the host cores")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "12")),
@@ -400,6 +524,22 @@ def main():
             if stale >= 3 and settle_frames >= 2 * args.inflight * args.settle_min_batches:
                 break
     timer = None if args.no_kernel_timer else ops.KernelTimer(sample_every=args.timer_sample)
+    # attributable lines: the shader clock the chip sustains over the timed region, read by one wave
+    # beside the workload, and the board power / sclk the driver exposes.  The sampler must stop on the pinned flag
+    # within one gap - checked here, outside the timed region; if it does not, it is not used.
+    clk = None
+    if rank == 0 and not args.no_clock_sampler:
+        try:
+            clk = ops.ClockSampler(dev)
+            clk.start()
+            time.sleep(0.01)
+            tq = time.perf_counter()
+            clk.stop()
+            if time.perf_counter() - tq > 0.05 or clk.summary() is None:
+                clk = None
+        except Exception:  # noqa: BLE001
+            clk = None
+    hw = HwmonSampler() if rank == 0 else None
     # Timed region: frames in flight on separate HIP streams.  By default their GPU phases
     # OVERLAP on the chip (blocks of one frame's kernels fill the tail / epilogue gaps of
     # another's: +15-25 % frames/s), which makes a single launch's start->stop duration
@@ -407,14 +547,27 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     ops.TIMER = timer
+    if clk is not None:
+        clk.start()
+    if hw is not None:
+        hw.start()
     t0 = time.perf_counter()
     # EXACTLY K steps = K full round trips; up to `inflight` frames overlap, all K complete
     # (streams synchronised, x_hat materialised) before the clock stops.
     results = pipe.map(round_trip, [frames[i % pool] for i in range(args.steps)])
+    if clk is not None:
+        clk.flag[0] = 1          # the sampler wave leaves within one 100 us gap; the sync below covers it
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    clocks = {"timed_region": clk.summary() if clk is not None else None,
+              "hwmon": hw.stop() if hw is not None else None,
+              "how": "timed_region: one wave beside the workload storing (100 MHz wall clock, shader-cycle counter) pairs "
+                     "every 100 us (cra5_clock_sampler_launch); effective clock = d cycles / d wall.  hwmon: amdgpu sysfs "
+                     "files read every 20 ms by a host thread (`static` = they did not move)"}
+    if clk is not None:
+        clk.running = False
     rows = [D.frame_stats(my_frames[i], out["strings"], out.get("n_escape", [-1])[0]) for i, (out, _) in enumerate(results)]
     assert all(bool(ok) for _, ok in results)
     # frames that re-use a pool tensor must reproduce its streams byte for byte (sizes + CRC): a race or a
@@ -468,6 +621,7 @@ def main():
                                  "numa_node": (h.get("numa_bind") or {}).get("numa_node")} for h in hosts],
                             "cpu_sets_disjoint": None if hosts is None else _disjoint([h["cpus"] for h in hosts])}},
         "warmup_settle_frames": settle_frames,
+        "clocks": clocks,
         "collectives": {"initialized": bool(torch.distributed.is_available() and torch.distributed.is_initialized()),
                         "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                         "data_path": "none (frames are independent)", "after_timed_region": "all_gather of int64[K,5] stats"},
@@ -586,16 +740,21 @@ def main():
                         ops.gemm_nt_split(ab, wb, out=ob)
                     torch.cuda.synchronize()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    if clk is not None:
+                        clk.start()
                     e0.record()
                     for _ in range(20):
                         ops.gemm_nt_split(ab, wb, out=ob)
                     e1.record()
+                    if clk is not None:
+                        torch.cuda.current_stream().synchronize()
+                        clk.stop()
                     torch.cuda.synchronize()
                     tb = e0.elapsed_time(e1) / 20 * 1e-3
                     ach_b = 2.0 * Mb * Nb * Kb / tb / 1e12
                     result["roofline"]["best_case_shape"] = {
                         "shape_mnk": [Mb, Nb, Kb], "achieved": ach_b, "frac": ach_b / result["roofline"]["peak"],
-                        "launch_ms": tb * 1e3,
+                        "launch_ms": tb * 1e3, "clock": clk.summary() if clk is not None else None,
                         "note": "same kernel, one exact round of tiles, K = 8192, 20 back-to-back launches on the current "
                                 "stream (256 x 256 tiles, 8 tile columns x CUs / 8 tile rows); the all-CU sustained clock, not the kernel, sets this "
                                 "figure (profiles/r04_active_cu_sweep.txt)"}
@@ -673,6 +832,11 @@ def main():
             shutil.rmtree(tmp, ignore_errors=True)
         except Exception as ex:  # noqa: BLE001
             result["api_single_frame"] = {"value": None, "error": repr(ex)}
+    if rank == 0 and world == 1 and not args.no_api_sample and args.quality == 268:
+        try:
+            result["api_pipelined"] = api_pipelined_sample(net, pipe, frames, args.inflight, args.api_frames)
+        except Exception as ex:  # noqa: BLE001
+            result["api_pipelined"] = {"value": None, "error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(

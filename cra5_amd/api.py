@@ -369,10 +369,13 @@ class cra5_api:
                         save_path=file_url)
         return self._pipeline(workers).map(one, list(zip(time_stamps, frames)))
 
-    def decode_batch(self, time_stamps=None, paths=None, return_format='de_normalized', out=None, workers=12):
+    def decode_batch(self, time_stamps=None, paths=None, return_format='de_normalized', out=None, workers=12, sink=None):
         """decode_from_bin for many frames.  Returns a list of HOST float32 arrays [C, H, W] (views of `out`
         [n, C, H, W] when given, fresh arrays otherwise); the D2H of each reconstruction goes through the
-        decoding thread's pinned buffer and overlaps the other frames' work."""
+        decoding thread's pinned buffer and overlaps the other frames' work.  `sink(i, frame)`: called on the decoding
+        thread with frame i as a [C, H, W] float32 view of that thread's PINNED buffer (valid until the call returns:
+        write it to disk, reduce it, copy it) instead of copying it out; the list then holds the sink's return values -
+        a long decode loop needs no [n, C, H, W] host array."""
         if paths is None:
             paths = [f'{self.local_root}/CRA5/{ts[:4]}/{ts}.bin' for ts in time_stamps]
         if return_format not in ('de_normalized', 'de_normlized', 'normalized'):
@@ -394,6 +397,8 @@ class cra5_api:
                 pin = self.net._pinned("api_x_out", (C, H, W), torch.float32)
                 pin.copy_(x_hat, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
+            if sink is not None:
+                return sink(i, pin.numpy())
             if out is not None:
                 np.copyto(out[i], pin.numpy())
                 return out[i]

@@ -159,3 +159,45 @@ extern "C" int cra5_copy_d2h_staged(void *dst_host, const void *src_dev, void *p
     if (e) (void)hipEventDestroy(e);
   return rc;   // 0 or the hipError_t, like every device launcher
 }
+
+// ---- shader-clock telemetry (bench.py: the sustained clock of the timed region travels with the JSON line) ----------
+namespace {
+__global__ __launch_bounds__(64) void clock_sampler_kernel(unsigned long long *buf, int n_max, int gap, const int *stop) {
+  if (threadIdx.x != 0) return;
+  unsigned long long next = wall_clock64();
+  int i = 0;
+  for (; i < n_max; ++i) {
+    unsigned long long w;
+    do {
+      __builtin_amdgcn_s_sleep(32);
+      w = wall_clock64();
+    } while (w < next);
+    buf[2 * i] = w;
+    buf[2 * i + 1] = clock64();
+    next = w + gap;
+    if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+      ++i;
+      break;
+    }
+  }
+  buf[2 * (size_t)n_max] = (unsigned long long)i;
+}
+__global__ void clock_stamp_kernel(unsigned long long *slot) {
+  if (threadIdx.x == 0) *slot = wall_clock64();
+}
+}  // namespace
+
+extern "C" int cra5_clock_sampler_launch(uint64_t *samples_dev, int n_max, int gap_ticks, const int *stop_flag_host,
+                                         void *stream) {
+  if (!samples_dev || !stop_flag_host || n_max <= 0 || gap_ticks <= 0) return CRA5_ERR_ARG;
+  hipLaunchKernelGGL(clock_sampler_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     reinterpret_cast<unsigned long long *>(samples_dev), n_max, gap_ticks, stop_flag_host);
+  return (int)hipGetLastError();
+}
+
+extern "C" int cra5_clock_stamp(uint64_t *slot_dev, void *stream) {
+  if (!slot_dev) return CRA5_ERR_ARG;
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     reinterpret_cast<unsigned long long *>(slot_dev));
+  return (int)hipGetLastError();
+}

@@ -17,6 +17,45 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class ClockSampler:
+    """Shader-clock telemetry (cra5_clock_sampler_launch): one wave beside the workload records (wall, cycle) pairs;
+    `summary()` gives the effective shader clock of the bracketed region.  bench.py runs it over the timed region so
+    that two JSON lines from two boxes can be told apart by the clock they sustained."""
+
+    def __init__(self, device, n_max=40000, gap_us=100):
+        self.n_max, self.gap = int(n_max), int(gap_us * 100)      # wall clock: 100 MHz
+        self.buf = torch.zeros(2 * self.n_max + 1, dtype=torch.int64, device=device)
+        self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.stream = torch.cuda.Stream(device=device)
+        self.running = False
+
+    def start(self):
+        self.flag[0] = 0          # (the kernel always writes its sample count when it leaves: nothing to clear)
+        check(lib().cra5_clock_sampler_launch(_p(self.buf), self.n_max, self.gap, ctypes.c_void_p(self.flag.data_ptr()),
+                                              ctypes.c_void_p(self.stream.cuda_stream)), "cra5_clock_sampler_launch")
+        self.running = True
+
+    def stop(self):
+        """Ends the sampling (the wave sees the pinned flag within one gap) and waits for it."""
+        self.flag[0] = 1
+        self.stream.synchronize()
+        self.running = False
+
+    def summary(self):
+        b = self.buf.cpu().numpy()
+        n = int(b[2 * self.n_max])
+        if n < 3:
+            return None
+        b = b[: 2 * n].reshape(n, 2)
+        import numpy as np
+        dw, dc = np.diff(b[:, 0]).astype(np.float64), np.diff(b[:, 1]).astype(np.float64)
+        ok = dw > 0
+        ghz = dc[ok] / (dw[ok] * 10.0)
+        return {"shader_ghz_mean": float(dc[ok].sum() / (dw[ok].sum() * 10.0)), "shader_ghz_p10": float(np.percentile(ghz, 10)),
+                "shader_ghz_median": float(np.median(ghz)), "shader_ghz_p90": float(np.percentile(ghz, 90)),
+                "samples": n, "span_ms": float((b[-1, 0] - b[0, 0]) / 1e5)}
+
+
 class KernelTimer:
     """Per-launch device timing with HIP events recorded on the launch stream
     (cra5_event_* in the C ABI).  Used by bench.py for the `roofline` object: it brackets

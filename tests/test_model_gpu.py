@@ -755,6 +755,9 @@ def test_api_batch_methods_pinned_pipeline(thin, dev, tmp_path):
         assert np.array_equal(d.cpu().numpy().reshape(8, 721, 1440), out[i]) and rec[i] is not None
     dn = api.decode_from_bin(stamps[1], return_format="normalized")["x_hat"]
     assert np.array_equal(dn.cpu().numpy().reshape(8, 721, 1440), rec_n[1])
+    # sink=: the consumer sees each frame in the decoding thread's pinned buffer (no [n, C, H, W] host array)
+    sums = api.decode_batch(stamps, workers=3, sink=lambda i, a: (i, float(a.astype(np.float64).sum())))
+    assert sums == [(i, float(out[i].astype(np.float64).sum())) for i in range(5)]
     # host staging takes what the reference's xarray path can hand over: float64 arrays, CPU tensors, non-contiguous
     # views - same bytes as the float32 frame
     f64 = frames[2].astype(np.float64)
