@@ -86,7 +86,7 @@ SIGNATURES = {
     "cra5_event_destroy": (c_int, [c_void_p]),
     "cra5_copy_h2d_staged": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
     "cra5_copy_d2h_staged": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
-    "cra5_clock_sampler_launch": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "cra5_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
     "cra5_clock_stamp": (c_int, [c_void_p, c_void_p]),
     "cra5_debug_range_counts": (c_int, [P(ctypes.c_uint64), c_int]),
 }

@@ -336,38 +336,78 @@ class cra5_api:
         xdev.copy_(pin, non_blocking=True)              # async H2D on this frame's stream
         return xdev
 
+    def _encode_one(self, ts, arr, save_root, write=True):
+        """One frame of the batch encode on the calling frame thread (its stream, its pinned / device buffers)."""
+        t0 = time.time()
+        if arr is None:
+            arr = self.read_data_from_nc(ts)
+        t1 = time.time()
+        with torch.no_grad():
+            x = self._stage_in(arr)
+            probe = self._finite_probe(x)
+            try:
+                y_str, z_str = self.net._compress_frame(x=x, mean=self._mean_flat, std=self._std_flat)
+            except FloatingPointError:
+                self._require_finite(probe)     # a non-finite INPUT is the caller's ValueError, as before
+                raise
+            self._require_finite(probe)
+        output = {"strings": [[y_str], [z_str]], "z_shape": torch.Size([self.net.Hz, self.net.Wz])}
+        t2 = time.time()
+        file_url = f'{save_root}/{ts.split("-")[0]}/{ts}.bin'
+        if write:
+            os.makedirs(os.path.dirname(file_url), exist_ok=True)
+            with Path(file_url).open("wb") as f:
+                f.write(binfmt.pack_bin(output["strings"], output["z_shape"]))
+        return dict(output=output, reading_time=t1 - t0, encoding_time=t2 - t1, saving_time=time.time() - t2,
+                    save_path=file_url)
+
     def encode_era5_batch(self, time_stamps, data=None, save_root=None, workers=12, write=True):
         """encode_era5_as_bin for many time stamps (`data`: matching list of host arrays, or None to read
         the NetCDF files).  Returns the list of per-frame dicts (same keys as encode_era5_as_bin)."""
         save_root = save_root or self.local_root
         self.net._require_gpu()
         frames = list(data) if data is not None else [None] * len(time_stamps)
+        return self._pipeline(workers).map(lambda it: self._encode_one(it[0], it[1], save_root, write),
+                                           list(zip(time_stamps, frames)))
+
+    def _decode_one(self, i, path, denorm, out=None, sink=None):
+        """One frame of the batch decode on the calling frame thread: .bin -> x_hat -> this thread's pinned buffer ->
+        `sink` / `out[i]` / a fresh array."""
+        C = self.net.cfg['out_chans']
+        H, W = self.net.cfg['img_size']
+        lstrings, shape = self._read_bin(path)
+        with torch.no_grad():
+            x_hat = self.net._decompress_frame(lstrings[0][0], lstrings[1][0], shape, True,
+                                               mean=self._mean_flat if denorm else None,
+                                               std=self._std_flat if denorm else None)
+            pin = self.net._pinned("api_x_out", (C, H, W), torch.float32)
+            pin.copy_(x_hat, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        if sink is not None:
+            return sink(i, pin.numpy())
+        if out is not None:
+            np.copyto(out[i], pin.numpy())
+            return out[i]
+        return pin.numpy().copy()
+
+    def roundtrip_batch(self, time_stamps, data=None, save_root=None, workers=12, sink=None, out=None,
+                        return_format='de_normalized'):
+        """The reference's test.py loop (test.py:14-59: encode_era5_as_bin then decode_from_bin per time stamp) as a
+        STREAM: every frame goes host array -> H2D -> g_a -> rANS -> .bin on disk -> .bin read -> rANS -> g_s -> D2H ->
+        `sink(i, frame)` / `out[i]`, `workers` frames in flight - the H2D of one frame, the D2H of another and the GPU /
+        rANS phases of the rest overlap.  Returns [(encode dict, sink's value | host array), ...]."""
+        save_root = save_root or self.local_root
+        if return_format not in ('de_normalized', 'de_normlized', 'normalized'):
+            raise ValueError(f"unknown return_format {return_format!r}")
+        denorm = return_format != 'normalized'
+        self.net._require_gpu()
+        frames = list(data) if data is not None else [None] * len(time_stamps)
 
         def one(item):
-            ts, arr = item
-            t0 = time.time()
-            if arr is None:
-                arr = self.read_data_from_nc(ts)
-            t1 = time.time()
-            with torch.no_grad():
-                x = self._stage_in(arr)
-                probe = self._finite_probe(x)
-                try:
-                    y_str, z_str = self.net._compress_frame(x=x, mean=self._mean_flat, std=self._std_flat)
-                except FloatingPointError:
-                    self._require_finite(probe)     # a non-finite INPUT is the caller's ValueError, as before
-                    raise
-                self._require_finite(probe)
-            output = {"strings": [[y_str], [z_str]], "z_shape": torch.Size([self.net.Hz, self.net.Wz])}
-            t2 = time.time()
-            file_url = f'{save_root}/{ts.split("-")[0]}/{ts}.bin'
-            if write:
-                os.makedirs(os.path.dirname(file_url), exist_ok=True)
-                with Path(file_url).open("wb") as f:
-                    f.write(binfmt.pack_bin(output["strings"], output["z_shape"]))
-            return dict(output=output, reading_time=t1 - t0, encoding_time=t2 - t1, saving_time=time.time() - t2,
-                        save_path=file_url)
-        return self._pipeline(workers).map(one, list(zip(time_stamps, frames)))
+            i, ts, arr = item
+            enc = self._encode_one(ts, arr, save_root, True)
+            return enc, self._decode_one(i, enc["save_path"], denorm, out, sink)
+        return self._pipeline(workers).map(one, [(i, ts, a) for i, (ts, a) in enumerate(zip(time_stamps, frames))])
 
     def decode_batch(self, time_stamps=None, paths=None, return_format='de_normalized', out=None, workers=12, sink=None):
         """decode_from_bin for many frames.  Returns a list of HOST float32 arrays [C, H, W] (views of `out`
@@ -387,23 +427,8 @@ class cra5_api:
         if out is not None and tuple(out.shape) != (len(paths), C, H, W):
             raise ValueError("`out` must be a float32 array of shape [n_frames, C, H, W]")
 
-        def one(item):
-            i, path = item
-            lstrings, shape = self._read_bin(path)
-            with torch.no_grad():
-                x_hat = self.net._decompress_frame(lstrings[0][0], lstrings[1][0], shape, True,
-                                                   mean=self._mean_flat if denorm else None,
-                                                   std=self._std_flat if denorm else None)
-                pin = self.net._pinned("api_x_out", (C, H, W), torch.float32)
-                pin.copy_(x_hat, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-            if sink is not None:
-                return sink(i, pin.numpy())
-            if out is not None:
-                np.copyto(out[i], pin.numpy())
-                return out[i]
-            return pin.numpy().copy()
-        return self._pipeline(workers).map(one, list(enumerate(paths)))
+        return self._pipeline(workers).map(lambda it: self._decode_one(it[0], it[1], denorm, out, sink),
+                                           list(enumerate(paths)))
 
     # ------------------------------------------------------------------ decode
     def _read_bin(self, bin_path):

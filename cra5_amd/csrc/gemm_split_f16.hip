@@ -146,11 +146,16 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // the wave index as a SCALAR: everything derived from it - the LDS-DMA destinations above all - stays in SGPRs
   // (m0 = s_add instead of v_add_u32 + v_readfirstlane_b32 + s_mov per 1-KB DMA instruction; 42 -> 28 instructions per
   // k-step of staging.  Measured, interleaved A/B: qkv 184 -> 175 us, fc1 279 -> 270, un-embed 1776 -> 1670)
-  const int lane = tid & 63, wave = (NPROD == 3) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  const int lane = tid & 63, wave = (NPROD >= 2) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int wave_dma = wave;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
-  const int nk_all = Kp / BK;
+  // NPROD == 2 (reduced-precision mode, wide form): a k-step is 64 k-values - the hi halves of TWO chunks - staged into
+  // the same 128-byte LDS rows the fp32-accurate mode uses ([32 hi of chunk 2s | 32 hi of chunk 2s + 1] instead of
+  // [32 hi | 32 lo]): same LDS-DMA instruction count, same fragment reads and the same ping-pong loop per k-step, two
+  // MFMAs per accumulator and 16-wide k-block instead of three, and K advances twice as fast.
+  constexpr int KSTEP = (NPROD == 2) ? 2 * BK : BK;
+  const int nk_all = Kp / KSTEP;
 
   const int tile = pid, ka = 0, kb = nk_all;
   // Tile order: the 32 work-groups an XCD runs at a time own 32 CONSECUTIVE tile numbers (xcd_remap), so tiles are
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // NPROD == 1 (reduced-precision mode): only the hi plane is staged - 16 rows x 64 B (the first half of
   // each line) per instruction into 64-byte LDS rows, piece p of row r at p ^ ((r >> 2) & 3): half the
   // LDS-DMA traffic of the fp32-accurate mode, which is what bounds this mode (1/3 of the MFMAs).
-  constexpr int ROWB = (NPROD == 3) ? 64 : 32;                   // halves per LDS row
+  constexpr int ROWB = (NPROD >= 2) ? 64 : 32;                   // halves per LDS row
   constexpr int GROUPS = (BM + BN) * ROWB / 512;                 // 1-KB groups per stage
   constexpr int NWAVE = WM * WN;
   constexpr int IPW = (GROUPS + NWAVE - 1) / NWAVE;              // LDS-DMA instructions per wave per k-step
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // CRA5_K_BARRIER wait with an explicit s_waitcnt vmcnt(0) (exactly the DMA of the tile the barrier publishes is
   // outstanding there).  The per-lane offsets are relative to the tile's first row (< 256 rows x the row pitch: the
   // launcher refuses pitches of 2^21 k-columns (2^22 halves) and more, far above anything the path has).
-  constexpr bool ASM_DMA = ((TM == 4 || TM == 3) && NPROD == 3 && WM == 2 && WN == 4 && !LONGK);
+  constexpr bool ASM_DMA = ((TM == 4 || TM == 3) && NPROD >= 2 && WM == 2 && WN == 4 && !LONGK);
   static_assert(!ASM_DMA || BM % (WM * WN * 8) == 0, "A / W staging instructions must not straddle");
   unsigned soff[IPW];
   unsigned long long curA = 0, curW = 0;
@@ -210,13 +215,16 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
       const int grow = gid * RPG;
       const bool isA = grow < BM;
       const int row_ = (isA ? grow : grow - BM) + lrow;
-      const int lpiece = (NPROD == 3) ? ((lane & 7) ^ ((row_ >> 1) & 7)) : ((lane & 3) ^ ((row_ >> 2) & 3));
+      const int lpiece = (NPROD >= 2) ? ((lane & 7) ^ ((row_ >> 1) & 7)) : ((lane & 3) ^ ((row_ >> 2) & 3));
+      // halves offset of the logical piece inside the row: contiguous [hi | lo] of one chunk, or (NPROD == 2) the hi
+      // half of chunk 0 (pieces 0-3) and of chunk 1 (pieces 4-7)
+      const int poffs = (NPROD == 2) ? ((lpiece >> 2) * 64 + (lpiece & 3) * 8) : lpiece * 8;
       if (isA)
-        src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + lpiece * 8 + (size_t)ka * 64;
+        src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + poffs + (size_t)ka * 64;
       else
-        src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + lpiece * 8 + (size_t)ka * 64;
+        src[q] = W + (size_t)min(n0 + row_, N - 1) * ldw + poffs + (size_t)ka * 64;
       if (ASM_DMA)
-        soff[q] = (unsigned)((((size_t)(isA ? (size_t)(min(m0 + row_, M - 1) - m0) * lda : (size_t)(min(n0 + row_, N - 1) - n0) * ldw)) + lpiece * 8) * 2);
+        soff[q] = (unsigned)((((size_t)(isA ? (size_t)(min(m0 + row_, M - 1) - m0) * lda : (size_t)(min(n0 + row_, N - 1) - n0) * ldw)) + poffs) * 2);
     }
   }
   if (ASM_DMA) {
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
 #else
 #define CRA5_GLDS16(SRC, DST) (void)(SRC)
 #endif
-#define CRA5_DMA_KSTRIDE 128
+#define CRA5_DMA_KSTRIDE (2 * KSTEP * 2)   /* bytes along a row per k-step: 128 B per 32-wide chunk (hi + lo) */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_STAGE_LOAD(BUF)                                                                   \
   {                                                                                            \
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
       _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                        \
         if (GROUPS % NWAVE == 0 || wave + q * NWAVE < GROUPS)                                  \
           CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave_dma + q * NWAVE) * 512);               \
-        src[q] += 64;                                                                          \
+        src[q] += 2 * KSTEP;                                                                   \
       }                                                                                        \
     }                                                                                          \
   }
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                          \
       if (GROUPS % NWAVE == 0 || wave + q * NWAVE < GROUPS)                                    \
         CRA5_GLDS16(src[q], lds + (BUF)*STAGE + (wave_dma + q * NWAVE) * 512);                 \
-      src[q] += 64;  /* next k-step: 128 B further along the row */                            \
+      src[q] += 2 * KSTEP;  /* next k-step: 128 B (one chunk) or 256 B further along the row */ \
     }                                                                                          \
   }
 #endif
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // fragment read offsets (halves) inside a stage: row * 64 + (piece ^ sw) * 8, piece = 2*kk + h (hi)
   // or 4 + 2*kk + h (lo); sw = (row >> 1) & 7 = (l31 >> 1) & 7 (sub-tile bases are multiples of 32 rows)
   // (NPROD == 1: 64-byte rows, 4 pieces, sw = (row >> 2) & 3)
-  const int sw = (NPROD == 3) ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
+  const int sw = (NPROD >= 2) ? ((l31 >> 1) & 7) : ((l31 >> 2) & 3);
   const int a_row = (wm * TM * 32 + l31) * ROWB;
   const int b_row = BM * ROWB + (wn * TN * 32 + l31) * ROWB;
   int poff[2], poff_lo[2];
@@ -292,17 +300,22 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   {                                                                                            \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                           \
       AH[i] = *reinterpret_cast<const half8 *>((ST) + a_row + i * SUB + poff[KK]);             \
-      if (NPROD == 3) AL[i] = *reinterpret_cast<const half8 *>((ST) + a_row + A_LO + i * SUB + poff_lo[KK]); \
+      if (NPROD >= 2) AL[i] = *reinterpret_cast<const half8 *>((ST) + a_row + A_LO + i * SUB + poff_lo[KK]); \
     }                                                                                          \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                           \
       BH[j] = *reinterpret_cast<const half8 *>((ST) + b_row + j * SUB + poff[KK]);             \
-      if (NPROD == 3) BL[j] = *reinterpret_cast<const half8 *>((ST) + b_row + B_LO + j * SUB + poff_lo[KK]); \
+      if (NPROD >= 2) BL[j] = *reinterpret_cast<const half8 *>((ST) + b_row + B_LO + j * SUB + poff_lo[KK]); \
     }                                                                                          \
   }
   // small terms first, plane-major: TM*TN independent accumulators between dependent MFMAs.
   // NPROD == 1 is the reduced-precision mode (BASELINE.json configs[4]): hi.hi only = plain f16.
 #define CRA5_MFMA_GROUP(AH, AL, BH, BL)                                                        \
   {                                                                                            \
+    if (NPROD == 2) {   /* "lo" registers = the hi halves of the step's second chunk: k-block KK + 2 */ \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BL[j], acc[i][j], 0, 0, 0); \
+    }                                                                                          \
     if (NPROD == 3) {                                                                          \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                           \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                         \
@@ -547,6 +560,11 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
     const bool wide = (M >= 1024 && N >= 2048);
     if (tiles128 < 256)
       return launch<2, 2, 1, 1, false, 2, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+    if (Kp % 64 == 0) {   // wide form: 64 k-values (the hi halves of two chunks) per k-step, the fp32-accurate mode's loop
+      if (wide)
+        return launch<2, 4, 4, 2, false, 2, 2>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+      return launch<2, 4, 3, 2, false, 2, 2>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
+    }
     if (wide)
       return launch<2, 4, 4, 2, false, 2, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
     return launch<2, 4, 3, 2, false, 2, 1>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st);
@@ -588,7 +606,8 @@ extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t 
   // second accumulator register set, so the big tiles stay spill-free.
   if (Kp > 8192 && C && !C_split && !(flags & CRA5_EPI_GELU)) {
     const int nchunk = (Kp + 8191) / 8192;
-    const int per = ((Kp / 32 + nchunk - 1) / nchunk) * 32;
+    const int gran = ((flags & CRA5_GEMM_HI_ONLY) && Kp % 64 == 0) ? 64 : 32;   // the wide reduced-precision form steps by 64
+    const int per = ((Kp / gran + nchunk - 1) / nchunk) * gran;
     for (int k0 = 0, i = 0; k0 < Kp; k0 += per, ++i) {
       const int kc = (Kp - k0 < per) ? Kp - k0 : per;
       const int f = ((i == 0) ? flags : CRA5_EPI_RES) | (flags & CRA5_GEMM_HI_ONLY);
@@ -650,7 +669,10 @@ extern "C" int cra5_gemm_nt_split_unembed(const uint16_t *A, int lda_kp, const u
   ue.Wp = Wp;
   const long lda = 2L * lda_kp, ldw = 2L * ldw_kp;
   int rc;
-  if (hi_only)
+  if (hi_only && Kp % 64 == 0)
+    rc = launch<2, 4, 4, 2, false, 2, 2, true>(A, lda, Wt, ldw, x, 0, nullptr, 0, nullptr, nullptr, 0, M, N, Kp, wscale_inv,
+                                               CRA5_GEMM_HI_ONLY, st, ue);
+  else if (hi_only)
     rc = launch<2, 4, 4, 2, false, 2, 1, true>(A, lda, Wt, ldw, x, 0, nullptr, 0, nullptr, nullptr, 0, M, N, Kp, wscale_inv,
                                                CRA5_GEMM_HI_ONLY, st, ue);
   else

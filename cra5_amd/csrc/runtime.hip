@@ -161,37 +161,33 @@ extern "C" int cra5_copy_d2h_staged(void *dst_host, const void *src_dev, void *p
 }
 
 // ---- shader-clock telemetry (bench.py: the sustained clock of the timed region travels with the JSON line) ----------
+// SHORT probes, never a resident sampler wave: HIP multiplexes its streams onto a handful of hardware queues and a
+// long-running kernel blocks every stream that shares its queue (a 4-second sampler wave stalled a quarter of the
+// frame streams of the pipeline until it left).  One probe = one wave for `window_ticks` of the 100 MHz wall clock.
 namespace {
-__global__ __launch_bounds__(64) void clock_sampler_kernel(unsigned long long *buf, int n_max, int gap, const int *stop) {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *slot, int window) {
   if (threadIdx.x != 0) return;
-  unsigned long long next = wall_clock64();
-  int i = 0;
-  for (; i < n_max; ++i) {
-    unsigned long long w;
-    do {
-      __builtin_amdgcn_s_sleep(32);
-      w = wall_clock64();
-    } while (w < next);
-    buf[2 * i] = w;
-    buf[2 * i + 1] = clock64();
-    next = w + gap;
-    if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
-      ++i;
-      break;
-    }
-  }
-  buf[2 * (size_t)n_max] = (unsigned long long)i;
+  const unsigned long long w0 = wall_clock64(), c0 = clock64();
+  unsigned long long w1;
+  do {
+    __builtin_amdgcn_s_sleep(8);
+    w1 = wall_clock64();
+  } while (w1 < w0 + window);
+  const unsigned long long c1 = clock64();
+  slot[0] = w0;
+  slot[1] = c0;
+  slot[2] = w1;
+  slot[3] = c1;
 }
 __global__ void clock_stamp_kernel(unsigned long long *slot) {
   if (threadIdx.x == 0) *slot = wall_clock64();
 }
 }  // namespace
 
-extern "C" int cra5_clock_sampler_launch(uint64_t *samples_dev, int n_max, int gap_ticks, const int *stop_flag_host,
-                                         void *stream) {
-  if (!samples_dev || !stop_flag_host || n_max <= 0 || gap_ticks <= 0) return CRA5_ERR_ARG;
-  hipLaunchKernelGGL(clock_sampler_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
-                     reinterpret_cast<unsigned long long *>(samples_dev), n_max, gap_ticks, stop_flag_host);
+extern "C" int cra5_clock_probe(uint64_t *slot4_dev, int window_ticks, void *stream) {
+  if (!slot4_dev || window_ticks <= 0 || window_ticks > 1000000) return CRA5_ERR_ARG;   // <= 10 ms per probe
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     reinterpret_cast<unsigned long long *>(slot4_dev), window_ticks);
   return (int)hipGetLastError();
 }
 

@@ -18,42 +18,60 @@ def _stream():
 
 
 class ClockSampler:
-    """Shader-clock telemetry (cra5_clock_sampler_launch): one wave beside the workload records (wall, cycle) pairs;
-    `summary()` gives the effective shader clock of the bracketed region.  bench.py runs it over the timed region so
-    that two JSON lines from two boxes can be told apart by the clock they sustained."""
+    """Shader-clock telemetry (cra5_clock_probe): a host thread launches a one-wave probe of `window_us` every
+    `period_ms` on its own stream while the workload runs; `summary()` gives the effective shader clock the probes saw.
+    bench.py runs it over the timed region so that two JSON lines from two boxes can be told apart by the clock they
+    sustained.  (Short probes, not a resident wave: a long kernel blocks the streams sharing its hardware queue.)"""
 
-    def __init__(self, device, n_max=40000, gap_us=100):
-        self.n_max, self.gap = int(n_max), int(gap_us * 100)      # wall clock: 100 MHz
-        self.buf = torch.zeros(2 * self.n_max + 1, dtype=torch.int64, device=device)
-        self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    def __init__(self, device, n_max=4096, period_ms=5.0, window_us=50):
+        self.n_max, self.period, self.window = int(n_max), float(period_ms) * 1e-3, int(window_us * 100)
+        self.buf = torch.zeros(4 * self.n_max, dtype=torch.int64, device=device)
         self.stream = torch.cuda.Stream(device=device)
-        self.running = False
+        self.n, self._on, self._th = 0, False, None
+
+    def probe(self):
+        """one probe on the sampler's stream (callers that pace the probes themselves)"""
+        if self.n >= self.n_max:
+            return
+        check(lib().cra5_clock_probe(ctypes.c_void_p(self.buf.data_ptr() + 32 * self.n), self.window,
+                                     ctypes.c_void_p(self.stream.cuda_stream)), "cra5_clock_probe")
+        self.n += 1
 
     def start(self):
-        self.flag[0] = 0          # (the kernel always writes its sample count when it leaves: nothing to clear)
-        check(lib().cra5_clock_sampler_launch(_p(self.buf), self.n_max, self.gap, ctypes.c_void_p(self.flag.data_ptr()),
-                                              ctypes.c_void_p(self.stream.cuda_stream)), "cra5_clock_sampler_launch")
-        self.running = True
+        import time
+        self.n, self._on = 0, True
+
+        def run():
+            while self._on and self.n < self.n_max:
+                self.probe()
+                time.sleep(self.period)
+        self._th = threading.Thread(target=run, daemon=True, name="cra5-clock")
+        self._th.start()
 
     def stop(self):
-        """Ends the sampling (the wave sees the pinned flag within one gap) and waits for it."""
-        self.flag[0] = 1
+        self._on = False
+        if self._th is not None:
+            self._th.join()
+            self._th = None
         self.stream.synchronize()
-        self.running = False
 
-    def summary(self):
-        b = self.buf.cpu().numpy()
-        n = int(b[2 * self.n_max])
-        if n < 3:
-            return None
-        b = b[: 2 * n].reshape(n, 2)
+    def summary(self, w0=None, w1=None):
+        """w0 / w1: keep the probes that lie inside this wall-clock window (cra5_clock_stamp values)."""
         import numpy as np
-        dw, dc = np.diff(b[:, 0]).astype(np.float64), np.diff(b[:, 1]).astype(np.float64)
-        ok = dw > 0
-        ghz = dc[ok] / (dw[ok] * 10.0)
-        return {"shader_ghz_mean": float(dc[ok].sum() / (dw[ok].sum() * 10.0)), "shader_ghz_p10": float(np.percentile(ghz, 10)),
+        if self.n < 1:
+            return None
+        b = self.buf.cpu().numpy()[: 4 * self.n].reshape(self.n, 4).astype(np.int64)
+        ok = b[:, 2] > b[:, 0]
+        if w0 is not None:
+            ok &= (b[:, 0] >= w0) & (b[:, 2] <= w1)
+        b = b[ok]
+        if len(b) < 1:
+            return None
+        ghz = (b[:, 3] - b[:, 1]) / ((b[:, 2] - b[:, 0]) * 10.0)
+        return {"shader_ghz_mean": float(ghz.mean()), "shader_ghz_p10": float(np.percentile(ghz, 10)),
                 "shader_ghz_median": float(np.median(ghz)), "shader_ghz_p90": float(np.percentile(ghz, 90)),
-                "samples": n, "span_ms": float((b[-1, 0] - b[0, 0]) / 1e5)}
+                "probes": int(len(b)), "probe_window_us": self.window / 100.0,
+                "span_ms": float((b[-1, 2] - b[0, 0]) / 1e5)}
 
 
 class KernelTimer:

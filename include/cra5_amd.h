@@ -347,12 +347,12 @@ int cra5_copy_h2d_staged(void *dst_dev, const void *src_host, void *pinned, size
 int cra5_copy_d2h_staged(void *dst_host, const void *src_dev, void *pinned, size_t bytes, size_t chunk_bytes,
                          int n_threads, void *stream);
 
-/* Shader-clock telemetry for bench.py (csrc/runtime.hip): ONE wave that sits on the chip beside the workload and
- * stores (100 MHz wall clock, shader-cycle counter) pairs into `samples_dev` [2 * n_max + 1 uint64, the last word =
- * samples taken] every `gap_ticks` wall ticks, until n_max samples or *stop_flag_host != 0 (a PINNED host word the GPU
- * polls: the caller stores 1 to end the sampling).  effective clock of an interval = d(cycles) / d(wall ticks) x 100 MHz.
- * cra5_clock_stamp writes the wall clock into one device word in stream order (brackets queued work). */
-int cra5_clock_sampler_launch(uint64_t *samples_dev, int n_max, int gap_ticks, const int *stop_flag_host, void *stream);
+/* Shader-clock telemetry for bench.py (csrc/runtime.hip).  cra5_clock_probe: ONE wave that stays for `window_ticks`
+ * of the 100 MHz wall clock (<= 10 ms) and stores {wall0, cycles0, wall1, cycles1} into slot4_dev[0..3]: effective
+ * shader clock of the window = (cycles1 - cycles0) / (wall1 - wall0) x 100 MHz, on the CU the wave landed on, beside
+ * whatever else runs.  Short probes on purpose: a resident sampler wave would block every stream that shares its
+ * hardware queue.  cra5_clock_stamp writes the wall clock into one device word in stream order (brackets queued work). */
+int cra5_clock_probe(uint64_t *slot4_dev, int window_ticks, void *stream);
 int cra5_clock_stamp(uint64_t *slot_dev, void *stream);
 
 /* Range audit of the split-f16 producers (csrc/split.h): out[0] = elements with |x| >= 65504 (clipped

@@ -475,11 +475,14 @@ def test_tiled_patch_gather_scatter_matches_generic(dev, C):
     assert torch.equal(raw.cpu(), ref_back)   # two-term sums: bit-exact
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (2048, 4096, 1024), (10368, 1024, 1024), (648, 360, 360)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (2048, 4096, 1024), (10368, 1024, 1024), (648, 360, 360),
+                                   (2048, 2048, 96), (1100, 2304, 160), (2048, 1024, 8192 + 64 * 5), (1536, 1024, 29480)])
 def test_gemm_hi_only_is_plain_f16(dev, M, N, K):
     """CRA5_GEMM_HI_ONLY (reduced-precision mode, BASELINE.json configs[4]): the product of the f16-rounded
     operands with fp32 accumulation - compared against exactly that in float64, and an order of magnitude
-    away from the fp32-accurate result so that the flag is known to take effect."""
+    away from the fp32-accurate result so that the flag is known to take effect.  Big tiles with Kp % 64 == 0 take the
+    wide form (64 k-values per k-step: the hi halves of two chunks per LDS row); Kp = 96 / 160 the 32-wide one; K >
+    8192 is chained in chunks that are multiples of 64."""
     g = torch.Generator().manual_seed(7 * M + N + K)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) * 0.02
@@ -663,7 +666,7 @@ def test_gemm_model_shapes_all_epilogues(dev, M, N, K):
 
 
 @pytest.mark.parametrize("C,K,denorm,hi", [(8, 128, True, False), (8, 128, False, False), (268, 1024, True, False),
-                                            (5, 96, True, True), (159, 1024, True, False)])
+                                            (5, 96, True, True), (159, 1024, True, False), (8, 1024, True, True)])
 def test_fused_unembed_equals_gemm_plus_overlap_add(dev, C, K, denorm, hi):
     """cra5_gemm_nt_split_unembed (GEMM epilogue -> reconstruction, overlap rows through the side buffer + fix-up
     kernel; vit_nlc.py:628-630, 666-669) against the two-call form it replaces - GEMM into the [tokens][C*110] column

@@ -755,6 +755,11 @@ def test_api_batch_methods_pinned_pipeline(thin, dev, tmp_path):
         assert np.array_equal(d.cpu().numpy().reshape(8, 721, 1440), out[i]) and rec[i] is not None
     dn = api.decode_from_bin(stamps[1], return_format="normalized")["x_hat"]
     assert np.array_equal(dn.cpu().numpy().reshape(8, 721, 1440), rec_n[1])
+    # roundtrip_batch: the test.py loop as a stream - same files, same reconstructions
+    rt = api.roundtrip_batch(stamps, data=frames, save_root=str(tmp_path / "RT"), workers=3)
+    for i in range(5):
+        assert open(rt[i][0]["save_path"], "rb").read() == open(res[i]["save_path"], "rb").read()
+        assert np.array_equal(rt[i][1], out[i])
     # sink=: the consumer sees each frame in the decoding thread's pinned buffer (no [n, C, H, W] host array)
     sums = api.decode_batch(stamps, workers=3, sink=lambda i, a: (i, float(a.astype(np.float64).sum())))
     assert sums == [(i, float(out[i].astype(np.float64).sum())) for i in range(5)]

@@ -44,39 +44,32 @@ def measure(fn, flop_issued, target_ms=400.0):
     torch.cuda.synchronize()
     per = e0.elapsed_time(e1) / 10
     n = max(20, int(target_ms / per))
-    samp = ops.ClockSampler(dev, n_max=4000, gap_us=20)      # 80 ms of samples
-    ns = samp.n_max
+    samp = ops.ClockSampler(dev, n_max=256, window_us=500)   # 500 us probes on a side stream
     stamps = torch.zeros(2, dtype=torch.int64, device=dev)
     main = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     best = None
     for rep in range(3):
         torch.cuda.synchronize()
+        samp.n = 0
         e0.record()
         for i in range(n):
-            if i == n // 5:                     # the sampler joins once the chip is busy; stamps bracket the rest
+            if i == n // 5:                     # the probes join once the chip is busy; stamps bracket the rest
                 lib().cra5_clock_stamp(ctypes.c_void_p(stamps.data_ptr()), main)
-                samp.start()
+                for _ in range(min(samp.n_max, int(0.5 * n * per / 0.5))):   # half the queue's length of probes
+                    samp.probe()
             fn()
         lib().cra5_clock_stamp(ctypes.c_void_p(stamps.data_ptr() + 8), main)
         e1.record()
-        torch.cuda.current_stream().synchronize()
-        samp.stop()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
-        raw = samp.buf.cpu().numpy().astype(np.int64)
-        cnt = int(raw[2 * ns])
-        b = raw[: 2 * cnt].reshape(cnt, 2)
         w0, w1 = (int(v) for v in stamps.cpu().numpy())
-        dw, dc = np.diff(b[:, 0]), np.diff(b[:, 1])
-        inside = (b[:-1, 0] >= w0) & (b[1:, 0] <= w1) & (dw > 0)   # intervals wholly inside the GEMM queue
-        ghz = (dc / (np.maximum(dw, 1) * 10.0))[inside]
-        ok = int(inside.sum()) >= 200
-        if not ok:
-            ghz = np.array([float("nan")])
-        g = float(np.median(ghz))
+        sm = samp.summary(w0, w1)
+        ok = sm is not None and sm["probes"] >= 8
+        g = sm["shader_ghz_median"] if ok else float("nan")
         row = dict(us_per_launch=us, tflops_issued=flop_issued / us / 1e6, shader_ghz=g,
-                   shader_ghz_p10=float(np.percentile(ghz, 10)), shader_ghz_p90=float(np.percentile(ghz, 90)),
-                   sampler_inside_queue=bool(ok), samples_inside=int(inside.sum()), launches=n)
+                   shader_ghz_p10=sm["shader_ghz_p10"] if ok else float("nan"),
+                   shader_ghz_p90=sm["shader_ghz_p90"] if ok else float("nan"),
+                   sampler_inside_queue=bool(ok), samples_inside=sm["probes"] if sm else 0, launches=n)
         row["flop_per_clk_frac"] = row["tflops_issued"] * 1e3 / g / PEAK_FLOP_PER_CLK
         if best is None or row["us_per_launch"] < best["us_per_launch"]:
             best = row
