@@ -345,6 +345,9 @@ class cra5_api:
         with torch.no_grad():
             x = self._stage_in(arr)
             probe = self._finite_probe(x)
+            # the frame has landed BEFORE this thread queues for a GPU-phase slot: a slot held while its stream waits 20 ms
+            # for the PCIe transfer is a third of the chip's concurrency gone (encode_era5_batch: 38 -> frames/s)
+            torch.cuda.current_stream().synchronize()
             try:
                 y_str, z_str = self.net._compress_frame(x=x, mean=self._mean_flat, std=self._std_flat)
             except FloatingPointError:

@@ -25,10 +25,42 @@ def _randn(rng, shape, std):
     return torch.from_numpy((rng.standard_normal(size=tuple(shape), dtype=np.float32) * np.float32(std)))
 
 
-def synth_tensor(key, shape, seed=0):
+# "matched" variant (round 5): the default set's h_s knows nothing about y, so sigma / mu miss |y - mu| by a wide margin -
+# 37 % of the y symbols leave their CDF row through the escape path and a 268 frame codes to 4.5 MB, far outside the
+# regime of a trained model (~1 MB, escapes a rarity).  Without training, the hyper-decoder can still be made to emit
+# sigma ~ rms(y) and mu ~ 0: its last LayerNorm gets a small gain and a fixed bias vector b, and the un-embed rows of
+# the sigma channels are MATCHED_SIGMA x b / |b|^2 plus a small token-dependent part (so that sigma = MATCHED_SIGMA
+# +- ~25 %: a spread of CDF-table rows like a trained model's), the mu rows a small random map.  Every other tensor is the
+# default set's: the transformer work per frame is identical, only the entropy side changes.
+MATCHED_SIGMA = 2.5          # rms(y) of the default set on N(0, 1) frames (bench.py `precision_f16.y_rms`: 2.49)
+_MATCHED_KEYS = ("h_s.norm.weight", "h_s.norm.bias", "h_s.final.weight")
+
+
+def _matched_tensor(key, shape, seed):
+    rng = _rng(seed, "matched/" + key)
+    if key == "h_s.norm.weight":
+        return 0.25 * (1.0 + _randn(rng, shape, 0.1))
+    if key == "h_s.norm.bias":
+        return _randn(rng, shape, 1.0)
+    # h_s.final.weight [F = zh*zw*2L, hd], rows ordered (p1 p2 c) (vit_nlc.py:665-680), c < L: sigma, c >= L: mu
+    F, hd = shape
+    b = _matched_tensor("h_s.norm.bias", (hd,), seed)
+    w = _randn(rng, shape, 1.0 / np.sqrt(hd))
+    w = w - torch.outer(w @ b, b) / float(b @ b)      # orthogonal to b: row . (gamma x^ + b) = constant + token part
+    cout = F // 16 if F % 16 == 0 else F          # zh * zw = 16 in both model sizes
+    c = torch.arange(F) % cout
+    is_sigma = (c < cout // 2).to(torch.float32).unsqueeze(1)
+    return is_sigma * (MATCHED_SIGMA * b / float(b @ b) + 2.4 * w) + (1.0 - is_sigma) * 0.4 * w
+
+
+def synth_tensor(key, shape, seed=0, variant="default"):
     """Value of parameter `key` (reference naming) with `shape`; None = leave as is."""
     if key.endswith(_SKIP):
         return None
+    if variant == "matched" and key in _MATCHED_KEYS:
+        return _matched_tensor(key, tuple(shape), seed)
+    if variant not in ("default", "matched"):
+        raise ValueError(f"unknown synthetic weight variant {variant!r}")
     rng = _rng(seed, key)
     shape = tuple(shape)
     leaf = key.rsplit(".", 1)[-1]
@@ -84,14 +116,24 @@ def synth_tensor(key, shape, seed=0):
 
 
 @torch.no_grad()
-def fill_state_dict(shapes, seed=0, device="cpu"):
+def fill_state_dict(shapes, seed=0, device="cpu", variant="default"):
     """shapes: {key: shape}. Returns {key: tensor} for every synthesised key."""
     out = {}
     for k, shp in shapes.items():
-        t = synth_tensor(k, shp, seed)
+        t = synth_tensor(k, shp, seed, variant)
         if t is not None:
             out[k] = t.to(torch.float32).to(device)
     return out
+
+
+@torch.no_grad()
+def apply_variant(net, seed=0, variant="matched"):
+    """Switch a net that carries the synthetic weights of `seed` between the "default" and the "matched" entropy variant:
+    only the three hyper-decoder tensors that differ are rewritten (the CDF tables do not depend on them)."""
+    own = net.state_dict()
+    for k in _MATCHED_KEYS:
+        own[k].copy_(synth_tensor(k, tuple(own[k].shape), seed, variant).to(own[k].device))
+    return net
 
 
 def synth_frame(channels, seed, H=721, W=1440, kind="normal"):
@@ -123,11 +165,11 @@ def thin_model_kwargs():
 
 
 @torch.no_grad()
-def load_synthetic(net, seed=0, update=True):
+def load_synthetic(net, seed=0, update=True, variant="default"):
     """Fill `net` (a VAEformer) with the deterministic synthetic weights and build its CDF
-    tables (`update(force=True)`)."""
+    tables (`update(force=True)`).  variant "matched": the entropy-representative set (see MATCHED_SIGMA)."""
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    sd = fill_state_dict(shapes, seed)
+    sd = fill_state_dict(shapes, seed, variant=variant)
     own = net.state_dict()
     for k, v in sd.items():
         own[k].copy_(v)

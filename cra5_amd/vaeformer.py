@@ -311,6 +311,8 @@ class VAEformer(nn.Module):
         # optional timeline of the GPU phases: a list receives (thread id, t_request, t_start, t_end)
         # per phase (tools/phase_timeline.py); None = off
         self.phase_log = None
+        # optional log of the host (rANS) phases: a list receives ("enc" | "dec_z" | "dec_y", seconds) per frame; None = off
+        self.host_log = None
         self.precision = os.environ.get("CRA5_PRECISION", "fp32")
         if self.precision not in ("fp32", "f16"):
             raise ValueError("CRA5_PRECISION must be 'fp32' or 'f16'")
@@ -961,6 +963,7 @@ class VAEformer(nn.Module):
             return (z_sym, host), self._finite(fl[:1]), self._finite(fl[1:-1])   # (the phase ended with a stream sync)
         keep = {}
         z_sym, host = self._range_guard(0, gpu_side, "compress")
+        t_host = time.perf_counter()
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
         z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
         if host[0] == "compact" and float(host[3][0]) != 0.0:
@@ -986,6 +989,8 @@ class VAEformer(nn.Module):
             n_esc = int(np.count_nonzero((v < 0) | (v >= ln[idx_np] - 2)))
         # symbols of the y stream coded through the escape path (rans_interface.cpp:120-160): the SURVEY 8(e) stats field
         self._tls.last_n_escape = n_esc
+        if self.host_log is not None:
+            self.host_log.append(("enc", time.perf_counter() - t_host))
         return y_str, z_str
 
     @torch.no_grad()
@@ -1026,7 +1031,10 @@ class VAEformer(nn.Module):
         zh, zw = int(shape[0]), int(shape[1])
         z_idx = eb._build_indexes((1, Cz, zh, zw))
         z_host = self._pinned("z_in", (Cz, zh * zw), torch.int32)
+        t_host = time.perf_counter()
         eb.decode_symbols(z_string, z_idx, out=z_host.numpy().reshape(-1))   # straight into pinned memory
+        if self.host_log is not None:
+            self.host_log.append(("dec_z", time.perf_counter() - t_host))
         with self._gpu_phase(light=True):
             z_sym = z_host.to(self.device, non_blocking=True)
             med, _ = eb.device_params()
@@ -1050,6 +1058,7 @@ class VAEformer(nn.Module):
                                      "engine, no fallback): the stream does not belong to this checkpoint, or the "
                                      "checkpoint is broken")
         y_host = None
+        t_host = time.perf_counter()
         if compact:
             y_host = self._pinned("y_in16", tuple(means.shape), torch.int16)
             try:
@@ -1062,6 +1071,8 @@ class VAEformer(nn.Module):
         if not compact:
             y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
             gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
+        if self.host_log is not None:
+            self.host_log.append(("dec_y", time.perf_counter() - t_host))
 
         def gpu_side():
             with self._gpu_phase(prio=2):

@@ -76,9 +76,9 @@ def build_thin():
                                       kwargs=dict(THIN_PRIOR_KW))).eval()
 
 
-def load_synth(net, seed):
+def load_synth(net, seed, variant="default"):
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
-    sd = synth.fill_state_dict(shapes, seed)
+    sd = synth.fill_state_dict(shapes, seed, variant=variant)
     missing, unexpected = torch.nn.Module.load_state_dict(net, sd, strict=False)
     assert not unexpected, unexpected
     net.update(force=True)
@@ -379,6 +379,89 @@ def stage_full():
     print("full done")
 
 
+def latent_ints(net, y, tag):
+    """Every integer of the reference's latent side for one frame's y, + the streams its compress() writes
+    (full268_ints-style): z symbols, CDF indexes, y symbols, stream hashes / bytes, margins, sub-sampled sigma / mu."""
+    import hashlib
+    o = {}
+    z = net.h_a(y)
+    med = net.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+    z_sym = net.entropy_bottleneck.quantize(z, "symbols", med)
+    z_hat, _ = net.entropy_bottleneck(z)
+    scales, means = net.h_s(z_hat).chunk(2, 1)
+    idx = net.gaussian_conditional.build_indexes(scales)
+    sym = net.gaussian_conditional.quantize(y, "symbols", means)
+    assert int(z_sym.abs().max()) < 32768 and int(sym.abs().max()) < 32768 and int(idx.max()) < 128
+    o["z_sym_full"] = z_sym.reshape(-1).numpy().astype(np.int16)
+    o["idx_full"] = idx.reshape(-1).numpy().astype(np.int8)
+    o["sym_full"] = sym.reshape(-1).numpy().astype(np.int16)
+    o.update(margins(net, y, z, scales, means))
+    step = 499 if y.numel() > 1000000 else 37
+    o["scales_sub"], o["means_sub"] = sub(scales, step), sub(means, step)
+    o["y_sub"], o["y_stats"] = sub(y, step), stats(y)
+    z_strings = net.entropy_bottleneck.compress(z)
+    y_strings = net.gaussian_conditional.compress(y, idx, means=means)
+    o["z_string"] = np.frombuffer(z_strings[0], dtype=np.uint8)
+    o["y_string_len"] = np.array([len(y_strings[0])])
+    o["y_string_sha256"] = np.frombuffer(hashlib.sha256(y_strings[0]).digest(), dtype=np.uint8)
+    if len(y_strings[0]) < 400000:
+        o["y_string"] = np.frombuffer(y_strings[0], dtype=np.uint8)
+    gc = net.gaussian_conditional
+    v = sym.reshape(-1) - gc._offset[idx.reshape(-1)]
+    o["n_escape"] = np.array([int(((v < 0) | (v >= gc._cdf_length[idx.reshape(-1)] - 2)).sum())])
+    print(tag, "y bytes", len(y_strings[0]), "z bytes", len(z_strings[0]), "escapes", int(o["n_escape"][0]), flush=True)
+    return o
+
+
+def _swap_variant(net, variant):
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items() if k in synth._MATCHED_KEYS}
+    sd = synth.fill_state_dict(shapes, 7, variant=variant)
+    torch.nn.Module.load_state_dict(net, sd, strict=False)
+
+
+def stage_ints(seeds=None):
+    """Round 5: reference integers + stream hashes (a) of the 268 fixture frame (seed 2) under the entropy-matched weight
+    variant (cra5_amd/synth.py MATCHED_SIGMA) -> full268_m_ints.npz, and (b) of the first two frames of the BENCHMARKED set
+    (bench.py: x_f = synth_frame(268, 1000 + f), f = 0, 1) under both variants -> bench{seed}_ints.npz /
+    bench{seed}_m_ints.npz.  One g_a pass per frame (~2-3 min each), the latent side once per variant."""
+    net = VAEformer(268).eval()
+    load_synth(net, seed=7)
+    for sd_x, name in ((2, "full268"), (1000, "bench1000"), (1001, "bench1001")):
+        if seeds and sd_x not in seeds:
+            continue
+        x = synth.synth_frame(268, seed=sd_x).unsqueeze(0)
+        t0 = time.time()
+        moments = net.quant_conv(net.g_a(x))
+        y = moments[:, : moments.shape[1] // 2].contiguous()
+        print(name, "g_a", time.time() - t0, flush=True)
+        for variant, suffix in (("default", ""), ("matched", "_m")):
+            if name == "full268" and variant == "default":
+                continue                       # full268_ints.npz exists (stage_full)
+            _swap_variant(net, variant)
+            o = latent_ints(net, y, name + suffix)
+            o["x_seed"] = np.array([sd_x])
+            np.savez_compressed(os.path.join(HERE, f"{name}{suffix}_ints.npz"), **o)
+        _swap_variant(net, "default")
+    print("ints done")
+
+
+def stage_thin_matched(seed=THIN_B_SEED):
+    """The thin model under the entropy-matched weight variant: every integer, the streams, the reference's own round trip."""
+    net = build_thin()
+    load_synth(net, seed=7, variant="matched")
+    x = synth.synth_frame(8, seed=seed).unsqueeze(0)
+    moments = net.quant_conv(net.g_a(x))
+    y = moments[:, : moments.shape[1] // 2].contiguous()
+    o = latent_ints(net, y, "thin_m")
+    o["x_seed"] = np.array([seed])
+    out = net.compress(x)
+    assert out["strings"][0][0] == o["y_string"].tobytes() and out["strings"][1][0] == o["z_string"].tobytes()
+    rec = net.decompress(out["strings"], out["z_shape"])
+    o["xhat_rt_sub"] = sub(rec["x_hat"], 1009)
+    np.savez_compressed(os.path.join(HERE, "thin_e2e_m.npz"), **o)
+    print("thin matched done")
+
+
 def build_159():
     """The 268 architecture with 159 variables through the reference's ddconfig route
     (model_version != 268): same kwargs as the hard-wired 268 config, in_chans = out_chans = 159."""
@@ -593,5 +676,5 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for s in a.stage:
         dict(small=stage_small, thin=stage_thin, thin_search=stage_thin_search, thin_cands=stage_thin_cands, thin2=stage_thin2, full=stage_full, full159=stage_full159, stats=stage_stats,
-             cnn=stage_cnn, cnn_relu=stage_cnn_relu,
+             cnn=stage_cnn, cnn_relu=stage_cnn_relu, ints=stage_ints, thin_matched=stage_thin_matched,
              thin64=lambda: stage_fp64("thin"), full64=lambda: stage_fp64("full"))[s]()

@@ -520,6 +520,123 @@ def test_full268_vs_reference_golden(big, dev, golden_dir, ledger):
     assert rmse(x_hat[0, 0, 720].cpu(), g["xhat_row720_c0"]) <= 1e-5
 
 
+@pytest.mark.parametrize("which,variant", [("full268_m_ints", "matched"), ("bench1000_ints", "default"),
+                                           ("bench1000_m_ints", "matched"), ("bench1001_ints", "default"),
+                                           ("bench1001_m_ints", "matched")])
+def test_full268_round5_reference_integers(big, dev, golden_dir, ledger, which, variant):
+    """Round 5 fixtures (make_golden.py --stage ints): the reference run on the 268 fixture frame under the
+    entropy-matched weight variant, and on the first two frames of the BENCHMARKED set (bench.py codes exactly these
+    tensors: synth_frame(268, 1000 + f)) under both variants.  Same ladder as test_full268_vs_reference_golden: y within
+    1e-5; the reference's z_hat injected into the product's h_s -> mu / sigma within 1e-5, every CDF index and y symbol
+    element-wise with every flip explained; the reference's integers through the device resolve kernel + host coder ==
+    the reference-python-written streams (sha256)."""
+    gi = np.load(f"{golden_dir}/{which}.npz")
+    seed = int(gi["x_seed"][0])
+    synth.apply_variant(big, seed=7, variant=variant)
+    try:
+        x = synth.synth_frame(268, seed=seed).unsqueeze(0).to(dev)
+        y = big.encode_latent(x, type='float')[0]
+        e_y = rmse(sub(y, 499), gi["y_sub"])
+        assert e_y <= 1e-5
+        s = big._latent_side_frame(y[0])
+        z_all = s["z_sym"].cpu().numpy().reshape(-1)
+        med_np = big.entropy_bottleneck.quantiles.detach()[:, 0, 1].cpu().numpy().astype(np.float64)
+        z_val = s["z"].double().cpu().numpy().reshape(256, -1) - med_np[:, None]
+        n_zflip = _explained_flips(f"{which} z symbols", z_all, gi["z_sym_full"], z_val, lambda k: k + 0.5, 1e-4)
+        sc_i, mu_i = _inject_reference_zhat(big, gi["z_sym_full"], dev)
+        e_mi, e_si = rmse(sub(mu_i, 499), gi["means_sub"]), rmse(sub(sc_i, 499), gi["scales_sub"])
+        assert e_mi <= 1e-5 and e_si <= 1e-5
+        gcm = big.gaussian_conditional
+        gci = ops.gaussian_conditional(sc_i, mu_i, gcm.scale_table, y=y[0].contiguous(), want=("idx", "sym"),
+                                       scale_bound=big._scale_bound(), lik_bound=gcm.likelihood_bound)
+        table = gcm.scale_table.double().cpu().numpy()
+        sc_np = np.maximum(sc_i.double().cpu().numpy(), big._scale_bound())
+        n_iflip = _explained_flips(f"{which} CDF indexes", gci["idx"].cpu().numpy(), gi["idx_full"], sc_np,
+                                   lambda k: table[np.clip(k, 0, table.size - 1)], 1e-5)
+        resid = (y[0].double() - mu_i.double()).cpu().numpy()
+        n_sflip = _explained_flips(f"{which} y symbols", gci["sym"].cpu().numpy(), gi["sym_full"], resid, lambda k: k + 0.5, 1e-4)
+        n_lat = gi["idx_full"].size
+        assert n_iflip <= 16 and n_sflip <= max(8, 3 * n_lat * 2 * 0.8 * e_y)
+        sr, raw, esc = ops.rans_resolve_symbols(torch.from_numpy(gi["sym_full"].astype(np.int32)).to(dev),
+                                                torch.from_numpy(gi["idx_full"].astype(np.int32)).to(dev),
+                                                gcm._quantized_cdf, gcm._cdf_length, gcm._offset)
+        y_ref_stream = ops.rans_encode_resolved(sr.cpu().numpy(), raw.cpu().numpy(), esc.cpu().numpy())
+        assert len(y_ref_stream) == int(gi["y_string_len"][0])
+        assert hashlib.sha256(y_ref_stream).digest() == gi["y_string_sha256"].tobytes()
+        # the compact records of the frame path on the same integers: same stream
+        sr_c, rec_c, ovf = ops.rans_resolve_symbols_compact(torch.from_numpy(gi["sym_full"].astype(np.int32)).to(dev),
+                                                            torch.from_numpy(gi["idx_full"].astype(np.int32)).to(dev),
+                                                            gcm._quantized_cdf, gcm._cdf_length, gcm._offset)
+        if float(ovf.float().sum()) == 0.0:
+            assert ops.rans_encode_resolved_compact(sr_c.cpu().numpy(), rec_c.cpu().numpy()) == y_ref_stream
+        # the product's own round trip of this frame: sizes in the reference's regime, lossless on its own integers
+        out = big.compress(x)
+        n_esc = big.last_n_escape()[0]
+        assert abs(len(out["strings"][0][0]) - int(gi["y_string_len"][0])) <= 256
+        assert abs(n_esc - int(gi["n_escape"][0])) <= 64
+        if variant == "matched":
+            assert n_esc < 0.01 * n_lat and len(out["strings"][0][0]) < 1.5e6
+        if n_zflip == 0:
+            assert out["strings"][1][0] == gi["z_string"].tobytes()
+        y_hat = big.decompress(out["strings"], out["z_shape"], return_format='latent')
+        assert torch.equal(torch.round(y_hat[0] - s["means"].reshape(y_hat[0].shape)).int().reshape(-1),
+                           s["y_sym"].reshape(-1).int())
+        print(f"{which}: y rmse {e_y:.2e}, z flips {n_zflip}, mu / sigma on the reference's z_hat {e_mi:.1e} / {e_si:.1e}, "
+              f"index flips {n_iflip}, symbol flips {n_sflip} of {n_lat}; y stream {len(y_ref_stream)} bytes, "
+              f"{int(gi['n_escape'][0])} escapes (product end to end: {len(out['strings'][0][0])} bytes, {n_esc} escapes)")
+        ledger.ran(f"268 {which} (frame seed {seed}, {variant} weights): mu / sigma <= 1e-5 on the reference's z_hat, every "
+                   "integer explained, sha256(y stream from the reference's integers) == reference-python-written stream's",
+                   f"{len(y_ref_stream)} bytes, {int(gi['n_escape'][0])} escapes, {n_iflip} index / {n_sflip} symbol flips")
+    finally:
+        synth.apply_variant(big, seed=7, variant="default")
+
+
+@pytest.fixture(scope="module")
+def thin_m(dev, golden_dir):
+    net = VAEformer(0, **synth.thin_model_kwargs())
+    synth.load_synthetic(net, seed=7, variant="matched")
+    net = net.to(dev)
+    g = np.load(f"{golden_dir}/thin_e2e_m.npz")
+    x = synth.synth_frame(8, seed=int(g["x_seed"][0])).unsqueeze(0).to(dev)
+    y = net.encode_latent(x, type='float')[0]
+    s = net._latent_side_frame(y[0])
+    torch.cuda.synchronize()
+    return net, g, x, y, s
+
+
+def test_thin_matched_variant_vs_reference(thin_m, ledger):
+    """The thin model under the entropy-matched weight variant (3.1 bits per latent, 7 escapes of 165 888 - a trained
+    model's regime) against the reference run on the same weights / frame: integers, both streams, and the reference's
+    own stream through the product's decompress()."""
+    net, g, x, y, s = thin_m
+    assert rmse(sub(y, 37), g["y_sub"]) <= 1e-5
+    assert rmse(sub(s["means"], 37), g["means_sub"]) <= 1e-5 and rmse(sub(s["scales"], 37), g["scales_sub"]) <= 1e-5
+    gc = net.gaussian_conditional
+    assert np.array_equal(s["z_sym"].cpu().numpy().reshape(-1), g["z_sym_full"].astype(np.int32))
+    table = gc.scale_table.double().cpu().numpy()
+    sc_np = np.maximum(s["scales"].double().cpu().numpy(), net._scale_bound())
+    n_iflip = _explained_flips("thin matched CDF indexes", s["idx"].cpu().numpy(), g["idx_full"], sc_np,
+                               lambda k: table[np.clip(k, 0, table.size - 1)], 1e-5)
+    resid = (y[0].double() - s["means"].double()).cpu().numpy()
+    n_sflip = _explained_flips("thin matched y symbols", s["y_sym"].cpu().numpy(), g["sym_full"], resid, lambda k: k + 0.5, 1e-4)
+    print(f"thin matched: index flips {n_iflip}, symbol flips {n_sflip} (reference margins y {g['margin_y'][0]:.1e}, "
+          f"scale {g['margin_scale'][0]:.1e})")
+    assert n_iflip <= 1 and n_sflip <= 1
+    out = net.compress(x)
+    assert out["strings"][1][0] == g["z_string"].tobytes()
+    assert net.last_n_escape()[0] <= int(g["n_escape"][0]) + 2 < 100
+    what = "thin matched variant (seed 162): y and z streams == reference-python-written streams; its .bin decodes to its x_hat"
+    if n_iflip == 0 and n_sflip == 0:
+        assert out["strings"][0][0] == g["y_string"].tobytes()
+        strings = [[g["y_string"].tobytes()], [g["z_string"].tobytes()]]
+        x_hat = net.decompress(strings, (18, 36))["x_hat"]
+        e = rmse(sub(x_hat, 1009), g["xhat_rt_sub"])
+        assert e <= 1e-5
+        ledger.ran(what, f"{len(out['strings'][0][0])} + {len(out['strings'][1][0])} bytes, x_hat rmse {e:.1e}")
+    else:
+        ledger.not_applicable(what, f"{n_iflip} index / {n_sflip} symbol flips (each within tolerance of its boundary)")
+
+
 def test_quality_159_vs_reference_golden(dev, golden_dir, ledger):
     """configs[1] of BASELINE.json: the 159-variable variant, encode_to_latent + latent_to_reconstruction,
     against the reference's own `VAEformer(0, ddconfig=... in_chans=159 ...)` on the same synthetic

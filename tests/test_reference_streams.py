@@ -59,6 +59,46 @@ def test_reference_integers_full_size_through_the_product_coder(golden_dir):
     assert np.array_equal(eb.decode_symbols(g["z_string"].tobytes(), z_idx), zs)
 
 
+ROUND5_INTS = ["full268_m_ints", "bench1000_ints", "bench1000_m_ints", "bench1001_ints", "bench1001_m_ints"]
+
+
+@pytest.mark.parametrize("which", ROUND5_INTS)
+def test_reference_integers_round5_fixtures_through_the_product_coder(golden_dir, which):
+    """Round 5 (tests/golden/make_golden.py --stage ints): the reference's integers of the 268 fixture frame under the
+    entropy-matched weight variant (`_m`: sigma ~ rms(y), a trained model's regime - ~1 MB streams, a handful of
+    escapes) and of the first two frames of the BENCHMARKED set (bench.py: synth_frame(268, 1000 + f)) under both
+    variants.  Product coder on those integers == the reference-python-written streams (oracle coder plugged in as
+    `compressai.ans`), and both decoders read them back."""
+    g = np.load(f"{golden_dir}/{which}.npz")
+    idx, sym = g["idx_full"].astype(np.int32), g["sym_full"].astype(np.int32)
+    assert idx.size == sym.size == 256 * 72 * 144
+    gc = _gc()
+    y = gc.encode_symbols(sym, idx)
+    assert len(y) == int(g["y_string_len"][0])
+    assert hashlib.sha256(y).digest() == g["y_string_sha256"].tobytes()
+    assert np.array_equal(gc.decode_symbols(y, idx), sym)
+    cdf, ln, off = gc.host_tables()
+    v = sym.astype(np.int64) - off[idx]
+    n_esc = int(np.count_nonzero((v < 0) | (v >= ln[idx] - 2)))
+    assert n_esc == int(g["n_escape"][0])
+    if which.endswith("_m_ints"):
+        assert n_esc < 0.01 * sym.size and len(y) < 1.5e6      # the matched variant's point: < 1 % escapes, ~1 MB
+    eb = _eb(golden_dir, "v268", 256, seed=7)
+    z_idx = eb._build_indexes((1, 256, 18, 36))
+    assert eb.encode_symbols(g["z_sym_full"].astype(np.int32), z_idx) == g["z_string"].tobytes()
+
+
+def test_reference_integers_thin_matched_through_the_product_coder(golden_dir):
+    g = np.load(f"{golden_dir}/thin_e2e_m.npz")
+    idx, sym = g["idx_full"].astype(np.int32), g["sym_full"].astype(np.int32)
+    gc = _gc()
+    assert gc.encode_symbols(sym, idx) == g["y_string"].tobytes()
+    assert np.array_equal(gc.decode_symbols(g["y_string"].tobytes(), idx), sym)
+    eb = _eb(golden_dir, "thin", 16, seed=7)
+    z_idx = eb._build_indexes((1, 16, 18, 36))
+    assert eb.encode_symbols(g["z_sym_full"].astype(np.int32), z_idx) == g["z_string"].tobytes()
+
+
 def test_reference_integers_thin_frame_a_through_the_product_coder(golden_dir):
     """Frame a of the thin model is the documented flip case (the product's h_s differs from the reference's in ONE of
     165 888 CDF indexes, tests/test_model_gpu.py pins which); on the reference's integers the coder is byte-exact."""
