@@ -666,9 +666,17 @@ bool balanced_plan(int L, int heads, BalArgs &b) {
     const int np = bal_piece_of(S, b.groups, (long)(g + 1) * b.nkt - 1) - bal_piece_of(S, b.groups, (long)g * b.nkt) + 1;
     if (np > b.maxp) b.maxp = np;
   }
-  // worth it only when every slot has at least one full pass of wave-tiles; a piece never spans more than two groups
-  // (n_grp <= groups), and every piece holds at least one step (S >= groups whenever there is a remainder)
-  return b.n_full >= 1 && (b.rem == 0 || (b.n_grp <= b.groups && S >= b.groups));
+  // worth it only when every slot has at least one full pass of wave-tiles, and every piece holds at least one step
+  // (S >= groups whenever there is a remainder)
+  if (!(b.n_full >= 1 && (b.rem == 0 || (b.n_grp <= b.groups && S >= b.groups)))) return false;
+  // The kernel walks a piece as AT MOST TWO (group, key range) segments (its segment builder has two slots): verify it
+  // for every piece of THIS plan instead of relying on n_grp <= groups alone - a piece that touched a third group would
+  // leave key ranges unvisited and the merge would read partials nobody wrote.
+  for (int c = 0; b.rem && c < b.groups; ++c) {
+    const long s0 = bal_cut(S, b.groups, c), s1 = bal_cut(S, b.groups, c + 1);
+    if (s1 > s0 && (s1 - 1) / b.nkt - s0 / b.nkt + 1 > 2) return false;
+  }
+  return true;
 }
 
 size_t balanced_ws_bytes(const BalArgs &b, int heads) {

@@ -319,6 +319,7 @@ class VAEformer(nn.Module):
         self._derived = {}
         self._derive_lock = threading.RLock()
         self._gpu_lock = threading.Lock()
+        self._fallback_lock = threading.Lock()     # range-guard re-runs on the exact-f32 engines: one frame at a time
         # gpu_slots = n > 0: at most n frames inside a GPU phase at a time (shared-stream mode only):
         # keeps a kernel's tail filled by another frame's blocks without letting ALL frames fall
         # into the host (rANS) phase together, which idles the GPU.  0 = unlimited.
@@ -409,10 +410,18 @@ class VAEformer(nn.Module):
                 "exact-f32 engines: the input or the weights are non-finite" if self.gemm_mode == "f32" else
                 "CRA5_RANGE_GUARD=0: a split-f16 activation left the f16 range, or the input is non-finite") + ")")
         import warnings
+        with self._gpu_lock:                      # (12 frame threads share the counters)
+            self.range_fallbacks[side] += 1
+            n_fb = sum(self.range_fallbacks)
+        # the count is part of the text: Python shows a repeated identical warning once per call site, and EVERY fallback
+        # should be visible - a checkpoint that sends many frames here runs at the exact-f32 engines' speed (~1/4)
         warnings.warn(f"{what}: non-finite values with the split-f16 engines (an activation beyond 65 504, csrc/split.h) - "
-                      "re-running this frame on the exact-f32 engines", RuntimeWarning, stacklevel=3)
-        self.range_fallbacks[side] += 1
-        with self._exact_f32_engines():
+                      f"re-running this frame on the exact-f32 engines (fallback #{n_fb} of this model)", RuntimeWarning,
+                      stacklevel=3)
+        # Fallbacks run ONE AT A TIME: the exact-f32 engines bring their own per-thread fp32 workspaces (qkv 127 MB, hidden
+        # 170 MB, un-embed columns 315 MB for the 268 model) and, on first use, fp32 copies of every g_a / g_s weight
+        # (1.6 GB, built once under _derive_lock) - bounded extra memory however many of the in-flight frames overflow.
+        with self._fallback_lock, self._exact_f32_engines():
             res, ok, ok_h = run()
         if not (bool(ok) and (ok_h is None or bool(ok_h))):
             raise FloatingPointError(f"{what}: non-finite values with the exact-f32 engines too - the input frame (or the "
@@ -874,8 +883,11 @@ class VAEformer(nn.Module):
             with self._gpu_phase():
                 x_hat = self._decode_frame(y_hat, mean=mean, std=std)
                 # (the residual stream after the last block carries every upstream poison - token-wise, and the global
-                # attention spreads it; the final LayerNorm's own output is O(gamma * sqrt(D)) and cannot leave the range)
-                flag = self._to_host("ok1", self._probe(self._buf(f"t{D}", (self.Hp * self.Wp, D))))
+                # attention spreads it.  The final LayerNorm's split store is O(gamma * sqrt(D)): a checkpoint with
+                # |gamma| sqrt(D) >= 65 504, or a non-finite mean / std, poisons x_hat BEHIND that probe - a strided
+                # sample of the reconstruction itself (every 16th row and column of every channel: a poisoned token's
+                # 110-pixel patch or a bad channel statistic cannot miss it) is probed as well: ADVICE r4)
+                flag = self._to_host("ok1", self._probe(self._buf(f"t{D}", (self.Hp * self.Wp, D)), x_hat[:, ::16, ::16]))
             return x_hat, self._finite(flag), None
         return self._range_guard(1, run, "decode")
 
@@ -1085,7 +1097,8 @@ class VAEformer(nn.Module):
                     return y_hat, True, None
                 x_hat = self._decode_frame(y_hat, mean=mean, std=std)
                 flag = self._to_host("ok1", self._probe(self._buf(f"t{self.cfg['embed_dim']}",
-                                                                  (self.Hp * self.Wp, self.cfg['embed_dim']))))
+                                                                  (self.Hp * self.Wp, self.cfg['embed_dim'])),
+                                                        x_hat[:, ::16, ::16]))
             return x_hat, self._finite(flag), None
         return self._range_guard(1, gpu_side, "decompress")
 

@@ -52,6 +52,8 @@ def pytest_terminal_summary(terminalreporter):
         return
     tr = terminalreporter
     tr.section("parity ledger: conditional byte / integer comparisons")
+    tr.write_line('("reference-python-written stream" = written by the reference\'s own compress() Python with the oracle coder '
+                  'plugged in as `compressai.ans`: the reference\'s compiled coder cannot be built here - DESIGN.md section 2)')
     for e in _LEDGER:
         tr.write_line(("RAN            " if e["ran"] else "NOT APPLICABLE ") + e["check"] + (": " + e["detail"] if e["detail"] else ""))
     n_ran = sum(e["ran"] for e in _LEDGER)

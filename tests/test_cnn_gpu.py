@@ -64,17 +64,17 @@ def test_cnn_zoo_vs_reference_golden(dev, golden_dir, name, cls, ledger):
     assert rel(sub(rec, 5), g[f"{name}_xhat_rt"]) <= 1e-3
     if all(same):
         assert rel(sub(rec, 5), g[f"{name}_xhat_rt"]) <= 1e-5
-        ledger.ran(f"cnn {name}: streams == reference-written streams, round trip <= 1e-5", f"bytes {lens}")
+        ledger.ran(f"cnn {name}: streams == reference-python-written streams, round trip <= 1e-5", f"bytes {lens}")
     else:
-        ledger.not_applicable(f"cnn {name}: streams == reference-written streams", f"identical per stream: {same}")
+        ledger.not_applicable(f"cnn {name}: streams == reference-python-written streams", f"identical per stream: {same}")
     # ... and decoding the REFERENCE's streams gives the reference's reconstruction
     ref_strings = [[g[f"{name}_string{i}"].tobytes()] for i in range(len(out["strings"]))]
     if all(same) or name == "factorized":
         rec2 = net.decompress(ref_strings, out["shape"])["x_hat"]
         assert rel(sub(rec2, 5), g[f"{name}_xhat_rt"]) <= 1e-5
-        ledger.ran(f"cnn {name}: reference-written streams decode to the reference's reconstruction")
+        ledger.ran(f"cnn {name}: reference-python-written streams decode to the reference's reconstruction")
     else:
-        ledger.not_applicable(f"cnn {name}: reference-written streams decode to the reference's reconstruction",
+        ledger.not_applicable(f"cnn {name}: reference-python-written streams decode to the reference's reconstruction",
                               "needs bit-identical h_s indexes; streams differ")
 
 

@@ -78,8 +78,10 @@ def thin(dev):
 
 
 @pytest.fixture(scope="module")
-def thin_side(thin, dev):
-    x = synth.synth_frame(8, seed=2).unsqueeze(0).to(dev)
+def thin_side(thin, dev, golden_dir):
+    # frame a of the thin fixtures (thin_e2e.npz): the input seed travels with the fixture (round 5: 135, a frame on which
+    # product and reference agree on every integer; rounds 1-4 used seed 2, the documented one-index-flip frame)
+    x = synth.synth_frame(8, seed=int(np.load(f"{golden_dir}/thin_e2e.npz")["x_seed"][0])).unsqueeze(0).to(dev)
     y = thin.encode_latent(x, type='float')[0]
     s = thin._latent_side_frame(y[0], want_lik=True)
     torch.cuda.synchronize()
@@ -151,18 +153,13 @@ def test_thin_roundtrip_and_bitstreams(thin, thin_side, dev, golden_dir, tmp_pat
     assert strings2[0][0] == y_str and strings2[1][0] == z_str and shape2 == (18, 36)
     out2 = thin.compress_from_latent(y)
     assert out2["strings"][0][0] == y_str and out2["strings"][1][0] == z_str
-    # (4) versus the stream the REFERENCE python produced (with the oracle coder): identical when the integer
-    #     inputs are identical.  THIS frame (seed 2) is the documented flip case: since round 2's hyper-prior engine the
-    #     product differs from the reference in 1 of 165 888 CDF indexes (within float tolerance), so here the
-    #     comparison is reported through the ledger; it RUNS, un-conditionally, on the second fixture frame
-    #     (test_thin_b_* below).
-    # z symbols of this frame: identical to the reference's, all of them (a regression here fails, it does not move to a
-    # ledger line), hence the z stream is the reference-written one
+    # (4) versus the stream the REFERENCE python produced (with the oracle coder).  Round 5: frame a is a frame on which the
+    #     product agrees with the reference on EVERY integer (like frame b; rounds 1-4 used seed 2 with its one documented
+    #     index flip and reported these comparisons as not applicable): plain asserts, element-wise first so that a
+    #     regression names the integer that moved.
     assert torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1))
     assert z_str == g["z_string"].tobytes()
-    ledger.ran("thin frame a (seed 2): z stream == reference-written z stream")
-    # CDF indexes / y symbols element-wise against the reference's (idx_full / sym_full, round 4): the documented flip
-    # case is ONE index, one step, with the scale within 1e-5 of the table entry it crossed; no symbol flips
+    ledger.ran("thin frame a: z stream == reference-python-written z stream")
     table = gc.scale_table.double().cpu().numpy()
     sc_np = np.maximum(s["scales"].double().cpu().numpy(), thin._scale_bound())
     n_iflip = _explained_flips("thin a CDF indexes", s["idx"].cpu().numpy(), g["idx_full"], sc_np,
@@ -170,22 +167,15 @@ def test_thin_roundtrip_and_bitstreams(thin, thin_side, dev, golden_dir, tmp_pat
     resid = (y[0].double() - s["means"].double()).cpu().numpy()
     n_sflip = _explained_flips("thin a y symbols", s["y_sym"].cpu().numpy(), g["sym_full"], resid, lambda k: k + 0.5, 1e-4)
     print(f"thin frame a vs the reference run: CDF index flips {n_iflip}, y symbol flips {n_sflip} of {g['idx_full'].size}")
-    assert n_iflip <= 1 and n_sflip == 0        # pinned: round 3 measured exactly (1, 0); more is a regression
-    if n_iflip == 0:
-        assert y_str == g["y_string"].tobytes()
-        ledger.ran("thin frame a (seed 2): y stream == reference-written y stream")
-    else:
-        assert abs(len(y_str) - int(g["y_string_len"][0])) <= 64
-        ledger.not_applicable("thin frame a (seed 2): y stream == reference-written y stream",
-                              f"documented flip case: {n_iflip} of {g['idx_full'].size} CDF indexes one step off, scale within "
-                              "1e-5 of the table entry (the same comparison runs on frame b and, below, on the "
-                              "reference's integers)")
-    # the reference's integers through the device resolve kernel + host state-update loop: the reference-written stream
+    assert (n_iflip, n_sflip) == (0, 0)
+    assert y_str == g["y_string"].tobytes()
+    ledger.ran("thin frame a: y stream == reference-python-written y stream", f"{len(y_str)} bytes")
+    # the reference's integers through the device resolve kernel + host state-update loop: the reference-python-written stream
     sr, raw, esc = ops.rans_resolve_symbols(torch.from_numpy(g["sym_full"].astype(np.int32)).to(dev),
                                             torch.from_numpy(g["idx_full"].astype(np.int32)).to(dev),
                                             gc._quantized_cdf, gc._cdf_length, gc._offset)
     assert ops.rans_encode_resolved(sr.cpu().numpy(), raw.cpu().numpy(), esc.cpu().numpy()) == g["y_string"].tobytes()
-    ledger.ran("thin frame a (seed 2): y stream coded from the reference's integers == reference-written y stream")
+    ledger.ran("thin frame a: y stream coded from the reference's integers == reference-python-written y stream")
     # (5) full decode: x_hat from the stream == decode_latent(y_hat) exactly (deterministic kernels)
     xa = thin.decompress(out["strings"], out["z_shape"])["x_hat"]
     xb = thin.decode_latent(y_hat)
@@ -195,7 +185,7 @@ def test_thin_roundtrip_and_bitstreams(thin, thin_side, dev, golden_dir, tmp_pat
 
 # ---- second thin fixture frame (thin_e2e_b.npz, input seed 162): chosen by tests/golden/make_golden.py
 # stage_thin_search + tools/thin_seed_probe.py so that product, oracle and reference agree on EVERY integer of the
-# frame - the byte comparison with the reference-written stream and the cross-implementation decode are plain
+# frame - the byte comparison with the reference-python-written stream and the cross-implementation decode are plain
 # asserts here, no xfail, no `if`
 
 
@@ -230,7 +220,7 @@ def test_thin_b_streams_equal_the_reference_written_streams(thin, thin_b, ledger
     assert out["strings"][1][0] == g["z_string"].tobytes()
     assert hashlib.sha256(out["strings"][0][0]).digest() == g["y_string_sha256"].tobytes()
     assert out["strings"][0][0] == g["y_string"].tobytes()
-    ledger.ran("thin frame b (seed 162): y and z streams == reference-written streams",
+    ledger.ran("thin frame b (seed 162): y and z streams == reference-python-written streams",
                f"{len(out['strings'][0][0])} + {len(out['strings'][1][0])} bytes")
 
 
@@ -248,7 +238,7 @@ def test_thin_b_decodes_the_reference_stream(thin, thin_b, ledger):
     e = rmse(sub(x_hat, 1009), g["xhat_rt_sub"])
     print(f"thin frame b: x_hat decoded from the reference's stream vs the reference's own decode: rmse {e:.2e}")
     assert e <= 1e-5
-    ledger.ran("thin frame b (seed 162): reference-written .bin strings decode to the reference's y_hat / x_hat",
+    ledger.ran("thin frame b (seed 162): reference-python-written .bin strings decode to the reference's y_hat / x_hat",
                f"x_hat rmse {e:.1e}")
 
 
@@ -261,24 +251,13 @@ def test_thin_decodes_the_reference_stream(thin, thin_side, dev, golden_dir, led
     _, y, s = thin_side
     assert torch.equal(s["z_sym"].cpu().reshape(-1), torch.from_numpy(g["z_sym"]).reshape(-1))
     idx_ref = g["idx_full"].astype(np.int32)
-    idx_same = np.array_equal(s["idx"].cpu().numpy().reshape(-1), idx_ref)        # element-wise, not a histogram
+    assert np.array_equal(s["idx"].cpu().numpy().reshape(-1), idx_ref)        # element-wise, not a histogram
     strings = [[g["y_string"].tobytes()], [g["z_string"].tobytes()]]
-    if idx_same:
-        y_hat = thin.decompress(strings, (18, 36), return_format='latent')
-        ledger.ran("thin frame a (seed 2): reference-written stream decodes on this build")
-    else:
-        # documented flip case (1 of 165 888 indexes, pinned in test_thin_roundtrip_and_bitstreams): decompress() would
-        # desynchronise at that element.  The decoder itself is held to the reference-written stream with the
-        # REFERENCE's indexes injected; the means that de-quantise the symbols are the product's own.
-        ledger.not_applicable("thin frame a (seed 2): reference-written stream decodes on this build",
-                              "product and reference disagree on one CDF index of this frame (rounding flip)")
-        sym = thin.gaussian_conditional.decode_symbols(strings[0][0], idx_ref)
-        assert np.array_equal(sym, g["sym_full"].astype(np.int32))
-        y_hat = ops.gaussian_conditional(s["scales"].contiguous(), s["means"].contiguous(),
-                                         thin.gaussian_conditional.scale_table,
-                                         sym_in=torch.from_numpy(sym).to(dev).reshape(s["means"].shape),
-                                         want=("y_hat",))["y_hat"].reshape(1, 16, 72, 144)
-        ledger.ran("thin frame a (seed 2): reference-written stream decodes with the reference's CDF indexes injected")
+    y_hat = thin.decompress(strings, (18, 36), return_format='latent')
+    ledger.ran("thin frame a: reference-python-written stream decodes on this build")
+    # ... and the decoder alone on the reference's CDF indexes (what rounds 1-4 had to fall back to on the flip frame)
+    sym = thin.gaussian_conditional.decode_symbols(strings[0][0], idx_ref)
+    assert np.array_equal(sym, g["sym_full"].astype(np.int32))
     d = (sub(y_hat, 37) - torch.from_numpy(g["y_hat_sub"])).abs()
     assert float(d.max()) <= 1e-4, float(d.max())     # same symbols + means within fp32 noise
     sym_dec = torch.round(y_hat[0].reshape(-1) - s["means"].reshape(-1)).int().cpu().numpy()
@@ -473,11 +452,11 @@ def test_full268_vs_reference_golden(big, dev, golden_dir, ledger):
     y_ref_stream = ops.rans_encode_resolved(sr.cpu().numpy(), raw.cpu().numpy(), esc.cpu().numpy())
     assert len(y_ref_stream) == int(gi["y_string_len"][0])
     assert hashlib.sha256(y_ref_stream).digest() == gi["y_string_sha256"].tobytes()
-    ledger.ran("268 full size: sha256(y stream coded from the reference's integers) == reference-written y stream's",
+    ledger.ran("268 full size: sha256(y stream coded from the reference's integers) == reference-python-written y stream's",
                f"{len(y_ref_stream)} bytes through the device resolve kernel + cra5_rans_encode_resolved")
     z_idx_all = big.entropy_bottleneck._build_indexes((1, 256, 18, 36))
     assert big.entropy_bottleneck.encode_symbols(gi["z_sym_full"].astype(np.int32), z_idx_all) == g["z_string"].tobytes()
-    ledger.ran("268 full size: z stream coded from the reference's z symbols == reference-written z stream",
+    ledger.ran("268 full size: z stream coded from the reference's z symbols == reference-python-written z stream",
                f"{g['z_string'].size} bytes")
     p = _hs_from_synth(big, dev)
     e_h = rmse(sub(p, 499), g["hs_synth_sub"])
@@ -501,7 +480,7 @@ def test_full268_vs_reference_golden(big, dev, golden_dir, ledger):
                              gc._cdf_length.cpu().numpy(), gc._offset.cpu().numpy())
     assert torch.equal(back.reshape(-1), s["y_sym"].cpu().reshape(-1))
     sym_l1, idx_l1 = int(np.abs(hist - g["sym_hist"]).sum()), int(np.abs(idx_hist - g["idx_hist"]).sum())
-    # the product's OWN end-to-end streams equal the reference-written ones exactly when no integer flipped (the
+    # the product's OWN end-to-end streams equal the reference-python-written ones exactly when no integer flipped (the
     # comparison on the reference's integers ran above, un-conditionally)
     if n_zflip == 0:
         assert out["strings"][1][0] == g["z_string"].tobytes()
@@ -681,11 +660,15 @@ def test_quality_159_vs_reference_golden(dev, golden_dir, ledger):
     z_rms = float(np.sqrt(g["z_stats"][1] / s["z"].numel()))
     assert e_z <= 1e-5 * max(1.0, z_rms)
     assert z_mis <= max(4, int(3 * s["z"].numel() * 2 * 0.8 * e_z))      # flip probability 2|err| per element
+    # every z flip is one step across a .5 boundary within 1e-4 (a flip further away is a bug, not float noise)
+    med_np = net.entropy_bottleneck.quantiles.detach()[:, 0, 1].cpu().numpy().astype(np.float64)
+    z_val = s["z"].double().cpu().numpy().reshape(med_np.size, -1) - med_np[:, None]
+    assert _explained_flips("159 z symbols", s["z_sym"].cpu().numpy(), g["z_sym"], z_val, lambda k: k + 0.5, 1e-4) == z_mis
     if z_mis == 0:
         assert e_m <= 1e-5 and e_s <= 1e-5
         assert idx_mis <= 1 and sym_mis <= 1 and flips <= 1 and e_q <= 1e-5
-    else:
-        assert flips <= 2 and e_q <= 5e-3       # end to end: the bounded effect of a few z flips on y_hat
+    # (with z flips the end-to-end mu / sigma / y_hat of THIS run are not comparable - one flipped z symbol moves every mu
+    # by ~1e-3 through h_s's global attention; the float comparison proper runs next, on the reference's z_hat, at 1e-5)
     # the reference's z_hat (all 165 888 symbols are in the fixture) injected into the product's h_s: means / scales /
     # y_hat held to the float tolerance on exactly the reference's input, whatever z flips the end-to-end run has
     sc_i, mu_i = _inject_reference_zhat(net, g["z_sym"], dev)

@@ -104,7 +104,7 @@ def thin_oracle(golden_dir):
     sd = synth.fill_state_dict({k: tuple(v) for k, v in keys.items()}, seed=7)
     cfg = R.cfg_thin()
     tb = R.tables(sd, cbind.pmf_to_cdf)
-    x = synth.synth_frame(8, seed=2).unsqueeze(0)
+    x = synth.synth_frame(8, seed=int(np.load(f"{golden_dir}/thin_e2e.npz")["x_seed"][0])).unsqueeze(0)
     with torch.no_grad():
         out, y = R.compress(x, sd, cfg, tb, cbind.rans_encode)
         side = R.latent_side(y, sd, cfg, tb["scale_table"])

@@ -3,7 +3,7 @@
 `full268_ints.npz` / `thin_e2e.npz` hold every z symbol, CDF index and y symbol of frames the reference's Python ran
 (tests/golden/make_golden.py --stage full / thin, synthetic weights), next to the byte strings (or their sha256) the
 reference's `compress()` wrote for them (entropy_models.py:263-271, rans_interface.cpp:108-200).  Feeding those integers
-to `cra5_rans_encode_with_indexes` with the product's own CDF tables must reproduce the reference-written streams byte for
+to `cra5_rans_encode_with_indexes` with the product's own CDF tables must reproduce the reference-python-written streams byte for
 byte - at the full 2.65 M-latent size too, where the end-to-end product run differs from the reference in a handful of
 rounding flips (tests/test_model_gpu.py counts them) and a whole-stream comparison would otherwise never apply.
 """
@@ -100,8 +100,8 @@ def test_reference_integers_thin_matched_through_the_product_coder(golden_dir):
 
 
 def test_reference_integers_thin_frame_a_through_the_product_coder(golden_dir):
-    """Frame a of the thin model is the documented flip case (the product's h_s differs from the reference's in ONE of
-    165 888 CDF indexes, tests/test_model_gpu.py pins which); on the reference's integers the coder is byte-exact."""
+    """Frame a of the thin model (round 5: input seed 135, stored in the fixture; rounds 1-4: seed 2, the one-index-flip
+    frame): on the reference's integers the coder is byte-exact."""
     g = np.load(f"{golden_dir}/thin_e2e.npz")
     idx, sym = g["idx_full"].astype(np.int32), g["sym_full"].astype(np.int32)
     gc = _gc()

@@ -14,6 +14,7 @@ L.cra5_debug_gemm_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 # (name, M, N, K, gelu, res, split_out)
 SHAPES = [("qkv", 10368, 3072, 1024, False, False, True), ("proj", 10368, 1024, 1024, False, True, False),
           ("fc1", 10368, 4096, 1024, True, False, True), ("fc2", 10368, 1024, 4096, False, True, False)]
+HI = "--hi" in sys.argv        # reduced-precision mode (CRA5_GEMM_HI_ONLY: the wide 64-k-step form)
 if "--active" in sys.argv:
     # Power / clock experiment: ONE round of 256 x 256 tiles on 64 / 128 / 192 / 256 of the 256 CUs (N = 1024: 4 tile
     # columns; M = 256 r rows -> 4 r tiles), K = 8192 so that the round lasts ~0.6 ms.  If the chip is power-capped under
@@ -33,9 +34,9 @@ for name, M, N, K, gelu, res, so in SHAPES:
     sm = ops.SplitMat.empty(M, N, dev) if so else None
     def run():
         if so:
-            ops.gemm_nt_split(sa, sw, bias=bias, gelu=gelu, out_split=sm, want_f32=False)
+            ops.gemm_nt_split(sa, sw, bias=bias, gelu=gelu, out_split=sm, want_f32=False, hi_only=HI)
         else:
-            ops.gemm_nt_split(sa, sw, bias=bias, res=r, out=out)
+            ops.gemm_nt_split(sa, sw, bias=bias, res=r, out=out, hi_only=HI)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
