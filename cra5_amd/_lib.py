@@ -64,6 +64,7 @@ SIGNATURES = {
                                                c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "cra5_im2col_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cra5_col2im_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "cra5_probe_sums_f32": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "cra5_transpose_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cra5_pixel_shuffle_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cra5_conv_im2col_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 12 + [c_void_p]),

@@ -135,14 +135,14 @@ class cra5_api:
         xdev = self.net._buf("api_x_dev", tuple(arr.shape))
         return ops.copy_h2d_staged(xdev, arr, pin)
 
-    @staticmethod
-    def _finite_probe(frame):
-        """One reduction pass over the frame, asynchronous: NaN / inf anywhere make the sum non-finite."""
-        return frame.sum(dtype=torch.float32)
+    def _finite_probe(self, frame):
+        """One reduction pass over the frame (ops.probe_sums), asynchronous: NaN / inf anywhere make a partial sum
+        non-finite."""
+        return self.net._probe(frame, name="api_in")
 
     @staticmethod
     def _require_finite(probe):
-        if not bool(torch.isfinite(probe)):
+        if not bool(torch.isfinite(probe).all()):
             raise ValueError("the input frame holds NaN / inf values (masked NetCDF values are read as NaN): fill them "
                              "before encoding - the codec would turn them into arbitrary symbols")
 

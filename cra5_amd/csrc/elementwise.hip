@@ -351,6 +351,25 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
   }
 }
 
+// Finiteness probe of the range guard (cra5_amd/vaeformer.py: _range_guard): CRA5_PROBE_PARTIALS partial sums of
+// x[0], x[stride], x[2 stride], ... - one per block, written (not accumulated: no memset, no atomics, deterministic).  A
+// sum is non-finite as soon as one addend is (fp32 sums of O(1e7) bounded activations do not overflow): the host tests
+// the partials it copies back with the phase's other results.  Replaces the torch reductions / stack / cat kernels of
+// rounds 1-4 on the frame path.
+__global__ __launch_bounds__(256) void probe_sums_kernel(const float *__restrict__ x, size_t n, size_t stride,
+                                                         float *__restrict__ partials) {
+  const size_t cnt = (n + stride - 1) / stride;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x)
+    acc += x[i * stride];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  __shared__ float wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 // 'b h w (p1 p2 c) -> b c (h p1) (w p2)'
 __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float *__restrict__ lin, float *__restrict__ out,
                                                             int Hz, int Wz, int p1, int p2, int Cout) {
@@ -721,6 +740,12 @@ int cra5_col2im_f32(const float *cols, const float *mean, const float *stdv, flo
   const size_t total = (size_t)C * H * W;
   hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, cols, mean, stdv, x, C,
                      H, W, kh, kw, sh, sw, Hp, Wp, ldn);
+  return (int)hipGetLastError();
+}
+
+int cra5_probe_sums_f32(const float *x, size_t n, size_t stride, float *partials, void *stream) {
+  if (!x || !partials || n == 0 || stride == 0) return CRA5_ERR_ARG;
+  hipLaunchKernelGGL(probe_sums_kernel, dim3(CRA5_PROBE_PARTIALS), dim3(256), 0, (hipStream_t)stream, x, n, stride, partials);
   return (int)hipGetLastError();
 }
 

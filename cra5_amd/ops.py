@@ -496,6 +496,19 @@ def col2im(cols, C, kh, kw, sh, sw, Hp, Wp, mean=None, std=None, out=None):
     return out
 
 
+PROBE_PARTIALS = 256     # CRA5_PROBE_PARTIALS
+
+
+def probe_sums(x, out, stride=1):
+    """cra5_probe_sums_f32: PROBE_PARTIALS partial sums of the flat fp32 tensor `x` (every `stride`-th element) into the
+    fp32 device slice `out` [PROBE_PARTIALS]; non-finite anywhere in the sampled elements <=> a non-finite partial."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and out.is_cuda and out.dtype == torch.float32
+            and out.is_contiguous() and out.numel() == PROBE_PARTIALS):
+        raise TypeError("probe_sums takes a contiguous fp32 device tensor and a contiguous fp32 device slice of PROBE_PARTIALS")
+    check(lib().cra5_probe_sums_f32(_p(x), x.numel(), int(stride), _p(out), _stream()), "cra5_probe_sums_f32")
+    return out
+
+
 def transpose(x, out=None):
     _dev(x, out)
     R, Cc = x.shape

@@ -374,12 +374,18 @@ class VAEformer(nn.Module):
         finally:
             self._tls.engine_override = prev
 
-    @staticmethod
-    def _probe(*tensors):
-        """Device-side finiteness probe, asynchronous: ONE fp32 value per argument - its sum, which is non-finite as soon
-        as one addend is (fp32 sums of O(1e7) bounded activations do not overflow).  The caller copies the values to the
-        host with the phase's other results and tests them there (`_finite`): no isfinite / logical kernels."""
-        return torch.stack([t.sum(dtype=torch.float32) for t in tensors])
+    def _probe(self, *items, name="probe"):
+        """Device-side finiteness probe, asynchronous: ops.PROBE_PARTIALS partial sums per argument (a tensor, or (tensor,
+        stride) for a strided sample) written by ONE product kernel each into this thread's probe buffer - a sum is
+        non-finite as soon as one addend is (fp32 sums of O(1e7) bounded activations do not overflow).  The caller copies
+        the values to the host with the phase's other results and tests them there (`_finite`).  (Rounds 1-4 used torch
+        reductions + stack / cat here: the last torch compute kernels on the frame path.)"""
+        P = ops.PROBE_PARTIALS
+        buf = self._buf(f"{name}{len(items)}", (len(items) * P,))
+        for k, it in enumerate(items):
+            t, stride = it if isinstance(it, tuple) else (it, 1)
+            ops.probe_sums(t if t.is_contiguous() else t.contiguous(), buf[k * P:(k + 1) * P], stride)
+        return buf
 
     @staticmethod
     def _hs_parent(scales, means):
@@ -391,7 +397,7 @@ class VAEformer(nn.Module):
 
     @staticmethod
     def _finite(host_values):
-        return all(math.isfinite(float(v)) for v in host_values)
+        return bool(torch.isfinite(host_values).all())
 
     def _range_guard(self, side, run, what):
         """Run one frame's GPU work `run()` -> (result, finite flag [device bool], hyper flag or None).  A non-finite
@@ -885,9 +891,9 @@ class VAEformer(nn.Module):
                 # (the residual stream after the last block carries every upstream poison - token-wise, and the global
                 # attention spreads it.  The final LayerNorm's split store is O(gamma * sqrt(D)): a checkpoint with
                 # |gamma| sqrt(D) >= 65 504, or a non-finite mean / std, poisons x_hat BEHIND that probe - a strided
-                # sample of the reconstruction itself (every 16th row and column of every channel: a poisoned token's
-                # 110-pixel patch or a bad channel statistic cannot miss it) is probed as well: ADVICE r4)
-                flag = self._to_host("ok1", self._probe(self._buf(f"t{D}", (self.Hp * self.Wp, D)), x_hat[:, ::16, ::16]))
+                # sample of the reconstruction itself (every 257th pixel: a poisoned token's 268 x 110-pixel patch or a bad
+                # channel statistic cannot miss it) is probed as well: ADVICE r4)
+                flag = self._to_host("ok1", self._probe(self._buf(f"t{D}", (self.Hp * self.Wp, D)), (x_hat, 257)))
             return x_hat, self._finite(flag), None
         return self._range_guard(1, run, "decode")
 
@@ -950,8 +956,8 @@ class VAEformer(nn.Module):
             with self._gpu_phase(prio=0):
                 yy = y if y is not None else self._encode_y_frame(x, mean=mean, std=std)
                 s = self._latent_side_frame(yy.contiguous())
-                pr_y = self._probe(yy)
-                pr_h = self._probe(*self._hs_parent(s["scales"], s["means"]))
+                par = self._hs_parent(s["scales"], s["means"])
+                pr = self._probe(yy, *par)          # [y | mu, sigma]: PROBE_PARTIALS values each
                 z_sym = self._to_host("z_sym", s["z_sym"])
                 if self.resolve_on_gpu and self.compact_records:
                     # symbol -> (start | range, 16-bit escape record) against the CDF tables on the device:
@@ -966,19 +972,20 @@ class VAEformer(nn.Module):
                     host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
                 else:
                     host = ("plain", self._to_host("y_sym", s["y_sym"]), self._to_host("idx", s["idx"]))
-                # the three tiny results of the phase (finiteness probes of y and of mu / sigma, the compact records'
-                # overflow flag) travel as ONE small copy
-                extra = keep["ovf"].float() if "ovf" in keep else pr_y.new_zeros(1)
-                fl = self._to_host("enc_flags", torch.cat([pr_y, pr_h, extra]))
+                # the phase's small results: the finiteness probes of y and of mu / sigma in one copy, the compact
+                # records' overflow word in another (no torch cat / cast kernels on the frame path)
+                fl = self._to_host("enc_flags", pr)
+                ovf_h = self._to_host("enc_ovf", keep["ovf"]) if "ovf" in keep else None
             if host[0] == "compact":
-                host = host[:3] + (fl[-1:],)
-            return (z_sym, host), self._finite(fl[:1]), self._finite(fl[1:-1])   # (the phase ended with a stream sync)
+                host = host[:3] + (ovf_h,)
+            P = ops.PROBE_PARTIALS
+            return (z_sym, host), self._finite(fl[:P]), self._finite(fl[P:])   # (the phase ended with a stream sync)
         keep = {}
         z_sym, host = self._range_guard(0, gpu_side, "compress")
         t_host = time.perf_counter()
         z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
         z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
-        if host[0] == "compact" and float(host[3][0]) != 0.0:
+        if host[0] == "compact" and int(host[3][0]) != 0:
             # an escape payload beyond 12 bits (|symbol| thousands beyond its table row): this frame takes the 32-bit records
             with self._gpu_phase(light=True):
                 sr, raw, esc = ops.rans_resolve_symbols(keep["sym"].reshape(-1), keep["idx"].reshape(-1),
@@ -1098,7 +1105,7 @@ class VAEformer(nn.Module):
                 x_hat = self._decode_frame(y_hat, mean=mean, std=std)
                 flag = self._to_host("ok1", self._probe(self._buf(f"t{self.cfg['embed_dim']}",
                                                                   (self.Hp * self.Wp, self.cfg['embed_dim'])),
-                                                        x_hat[:, ::16, ::16]))
+                                                        (x_hat, 257)))
             return x_hat, self._finite(flag), None
         return self._range_guard(1, gpu_side, "decompress")
 

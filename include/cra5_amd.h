@@ -243,6 +243,12 @@ int cra5_col2im_f32(const float *cols, const float *mean, const float *std, floa
                     int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp, int ldn,
                     void *stream);
 
+/* Finiteness probe of the range guard: partials[b] = sum of x[i * stride] over block b's share of i = 0 .. ceil(n / stride)
+ * - 1, b = 0 .. CRA5_PROBE_PARTIALS - 1 (written, never accumulated: no memset, deterministic).  A partial is non-finite as
+ * soon as one addend is; the caller copies the partials to the host with the phase's other results and tests them there. */
+#define CRA5_PROBE_PARTIALS 256
+int cra5_probe_sums_f32(const float *x, size_t n, size_t stride, float *partials, void *stream);
+
 /* out[c][r] = in[r][c] (token-major <-> NCHW plumbing, vit_nlc.py:484, 684). */
 int cra5_transpose_f32(const float *in, int ld_in, float *out, int ld_out, int rows, int cols,
                        void *stream);
