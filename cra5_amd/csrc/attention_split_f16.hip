@@ -580,7 +580,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
             const int c0 = hoff + 32 * t + 16 * pr + 8 * h;          // first of this lane's 8 columns after the swap
             unsigned short *sp = srow + (c0 >> 5) * 64 + (c0 & 31);
             *reinterpret_cast<uint4 *>(sp) = make_uint4(ha0, ha1, hb0, hb1);
-            *reinterpret_cast<uint4 *>(sp + 32) = make_uint4(la0, la1, lb0, lb1);
+            // (reduced-precision mode: the proj GEMM reads the hi plane only)
+            if (!HI) *reinterpret_cast<uint4 *>(sp + 32) = make_uint4(la0, la1, lb0, lb1);
           }
         }
       }

@@ -373,6 +373,12 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     CRA5_TRACE(1);
+    // (NPROD == 2, the reduced-precision wide form, runs the same loop: its 16-MFMA phases (512 cycles) no longer cover the
+    // partner's read phase (~870 cycles: 3470 per k-step for 2048 of MFMAs, tools/gemm_trace.py --hi).  Two re-arrangements
+    // were measured and lost - two phases per k-step with double fragment registers (qkv tile main loop 35.4 vs 29.2 us:
+    // the eight LDS-DMA issues per wave and k-step dominate a read phase, whoever issues them) and the DMA issued at the top
+    // of the first MFMA phase (31.7 us): DESIGN.md section 9.)
+    {
     if (wm == 1) CRA5_PP_BARRIER;   // the second group runs one interval behind
     for (int kt = 0; kt < nk; ++kt) {
       const unsigned short *st = lds + (kt & 1) * STAGE;
@@ -390,6 +396,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
       if (rows_live) CRA5_MFMA_GROUP(f0ah, f0al, f0bh, f0bl);
       if (wm == 0) CRA5_PP_DRAIN;
       CRA5_PP_BARRIER;
+    }
     }
     if (wm == 0) CRA5_PP_BARRIER;
   } else {

@@ -130,7 +130,9 @@ int cra5_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *
 #define CRA5_EPI_GELU 2
 #define CRA5_EPI_RES 4
 /* cra5_gemm_nt_split only: reduced-precision mode, hi.hi product only (plain f16 operands, fp32
- * accumulate, 1 MFMA per product instead of 3) - BASELINE.json configs[4], RMSE-gated. */
+ * accumulate, 1 MFMA per product instead of 3) - BASELINE.json configs[4], RMSE-gated.  Only the hi plane of
+ * A / W is read, and only the hi plane of C_split is WRITTEN (its lo halves keep whatever they held: a
+ * consumer of that matrix must run in this mode too). */
 #define CRA5_GEMM_HI_ONLY 8
 int cra5_gemm_nt_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc,
                      const float *bias, const float *res, int ldr, int M, int N, int K,
@@ -184,7 +186,8 @@ int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out
  * Requires head dim 64 and wh*ww % 32 == 0 (the 576-token windows and the 10 368-token global
  * attention); a window that is not the whole grid must have <= 1152 tokens (CRA5_ERR_ARG otherwise);
  * other shapes use cra5_window_attention_f32.  hi_only != 0: reduced-precision mode
- * (plain f16 q/k/v/p operands, 8 MFMAs per tile instead of 24; fp32 softmax statistics). */
+ * (plain f16 q/k/v/p operands, 8 MFMAs per tile instead of 24; fp32 softmax statistics; only the hi plane of
+ * out_split is written). */
 int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
                                 float *out, uint16_t *out_split, int out_kp, int C, int heads,
                                 int H, int W, int wh, int ww, float scale, int hi_only,
