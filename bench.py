@@ -636,6 +636,13 @@ def main():
         clk.start()
     if hw is not None:
         hw.start()
+    # two marker launches (clock_stamp_kernel) bracket the timed region in a rocprofv3 kernel trace: tools/trace_concurrency.py
+    # restricts its GPU-busy / concurrency figures to the kernels between them
+    import ctypes
+    from cra5_amd._lib import lib as _cra5_lib
+    region_marks = torch.zeros(2, dtype=torch.int64, device=dev)
+    _cra5_lib().cra5_clock_stamp(ctypes.c_void_p(region_marks.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.current_stream().synchronize()
     t0 = time.perf_counter()
     # EXACTLY K steps = K full round trips; up to `inflight` frames overlap, all K complete
     # (streams synchronised, x_hat materialised) before the clock stops.
@@ -645,6 +652,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
+    _cra5_lib().cra5_clock_stamp(ctypes.c_void_p(region_marks.data_ptr() + 8), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     ops.TIMER = None
     net.host_log = None
     clocks = {"timed_region": clk.summary() if clk is not None else None,

@@ -9,8 +9,15 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 t0, t1 = ev[0][0], max(e[1] for e in ev)
-lo = t0 + (t1 - t0) * 0.5
-sel = [e for e in ev if e[0] >= lo]
+marks = [e for e in ev if "clock_stamp_kernel" in e[2]]
+if len(marks) >= 2:
+    # bench.py brackets its TIMED REGION with two clock_stamp_kernel launches: everything below is about that region only
+    lo, hi = marks[0][1], marks[1][0]
+    sel = [e for e in ev if e[0] >= lo and e[1] <= hi and "clock_stamp_kernel" not in e[2] and "clock_probe_kernel" not in e[2]]
+    print(f"timed region (between the two clock_stamp_kernel marks): {(hi - lo) / 1e6:.1f} ms, {len(sel)} kernels")
+else:
+    lo = t0 + (t1 - t0) * 0.5
+    sel = [e for e in ev if e[0] >= lo]
 pts = []
 for i, (s, e, n) in enumerate(sel):
     pts.append((s, 1, i))
@@ -35,6 +42,20 @@ for t, d, i in pts:
     else:
         active.discard(i)
 wall = pts[-1][0] - pts[0][0]
+if len(marks) >= 2:
+    # idle = no kernel running, measured against the whole marked region (incl. its edges)
+    busy = sum(v for k, v in level_time.items() if k > 0)
+    gaps = []
+    cur_end = lo
+    for s_, e_, n_ in sel:
+        if s_ > cur_end:
+            gaps.append((s_ - cur_end, n_))
+        cur_end = max(cur_end, e_)
+    if hi > cur_end:
+        gaps.append((hi - cur_end, "<end of region>"))
+    gaps.sort(reverse=True)
+    print(f"GPU busy (union of kernels) {busy / 1e6:.1f} ms = {100 * busy / (hi - lo):.1f} % of the region; idle {100 - 100 * busy / (hi - lo):.1f} %; "
+          f"largest gaps (us, kernel that follows): " + ", ".join(f"{g / 1e3:.0f} {n[:40]}" for g, n in gaps[:5]))
 print("concurrency level -> share of the wall clock:", {k: round(100 * v / wall, 1) for k, v in sorted(level_time.items())})
 
 
