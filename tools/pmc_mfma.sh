@@ -1,10 +1,10 @@
 #!/bin/bash
 # GPU box: MFMA-pipe utilisation per kernel (separate PMC pass, --kernel-trace only) -> gpurun_out/ROUND/ROUND_mfma_util.json
 #   tools/pmc_mfma.sh [ROUND=r03]
-T=${1:-r03}; export CRA5_PROF_TAG=$T; mkdir -p $GRAFT_REPO_ROOT/gpurun_out/$T
+T=${1:-r05}; export CRA5_PROF_TAG=$T; mkdir -p $GRAFT_REPO_ROOT/gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --exclusive --inflight 1 --no-kernel-timer > $R/gpurun_out/pmc_mfma.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --no-matched-sample --exclusive --inflight 1 --no-kernel-timer > $R/gpurun_out/pmc_mfma.log 2>&1 < /dev/null
 cd $R
 python - <<'PY'
 import collections, csv, json

@@ -3,16 +3,16 @@
 #   tools/profile_bench.sh [ROUND=r03]  -> gpurun_out/ROUND/ : copy the *_kernel_stats.csv / *.json summaries into profiles/
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-T=${1:-r03}
+T=${1:-r05}
 O=$R/gpurun_out/$T
 rm -rf $O; mkdir -p $O
 # 1. the default bench command (overlapping GPU phases, 12 frames in flight)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o bench -- python $R/bench.py --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case > $O/bench_default.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o bench -- python $R/bench.py --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --no-matched-sample > $O/bench_default.log 2>&1 < /dev/null
 # 2. exclusive GPU phases: every launch alone on the chip (the durations the roofline object uses)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_excl -o bench -- python $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --exclusive > $O/bench_excl.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_excl -o bench -- python $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --no-matched-sample --exclusive > $O/bench_excl.log 2>&1 < /dev/null
 # 3. HBM-side bytes per kernel: one counter per pass, --kernel-trace only
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_traffic_$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --exclusive --inflight 1 --no-kernel-timer > $O/pmc_traffic_$c.log 2>&1 < /dev/null
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_traffic_$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --no-matched-sample --exclusive --inflight 1 --no-kernel-timer > $O/pmc_traffic_$c.log 2>&1 < /dev/null
 done
 cd $R
 cp $(find $O/prof_default -name '*kernel_stats.csv' | head -1) $O/${T}_bench_default_kernel_stats.csv
