@@ -296,7 +296,9 @@ def api_pipelined_sample(net, pipe, frames, inflight, n):
     net.gpu_exclusive = False
     tmp = tempfile.mkdtemp(prefix="cra5_bench_pipe_")
     try:
-        api = cra5_api(local_root=tmp, device="cuda", weights=net)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):        # (the reference API prints its device: stdout is the JSON line's)
+            api = cra5_api(local_root=tmp, device="cuda", weights=net)
         api._pipe = pipe                                     # the bench's frame threads (their workspaces exist already)
         n_host = min(8, len(frames))
         host = [(frames[i][0] * api.std + api.mean).cpu().numpy() for i in range(n_host)]
@@ -709,7 +711,7 @@ def main():
                             "per_rank": None if hosts is None else [
                                 {"rank": h["rank"], "n_cpus": h["n_cpus"], "cpu_span": [h["cpus"][0], h["cpus"][-1]] if h["cpus"] else [],
                                  "threads": h["threads"], "threads_outside_mask": h["threads_outside_mask"],
-                                 "outside_names": h.get("outside_names"),
+                                 "outside_names": h.get("outside_names"), "gpu_check": h.get("gpu_check"),
                                  "numa_node": (h.get("numa_bind") or {}).get("numa_node")} for h in hosts],
                             "cpu_sets_disjoint": None if hosts is None else _disjoint([h["cpus"] for h in hosts])}},
         "warmup_settle_frames": settle_frames,
@@ -934,7 +936,9 @@ def main():
             from cra5_amd.api import cra5_api
             net.gpu_exclusive = False
             tmp = tempfile.mkdtemp(prefix="cra5_bench_")
-            api = cra5_api(local_root=tmp, device="cuda", weights=net)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):    # (the reference API prints its device: stdout is the JSON line's)
+                api = cra5_api(local_root=tmp, device="cuda", weights=net)
             host = (frames[0][0] * api.std + api.mean).cpu().numpy()      # physical units, pageable host memory
             ts, te, td = "2024-06-01T00:00:00", [], []
             for _ in range(4):

@@ -56,6 +56,8 @@ class cra5_api:
         self._std_flat = self.std.reshape(-1).contiguous()
         self.channels_to_vname, self.vname_to_channels = self.channel_vname_mapping()
         self.local_root = local_root or f'{os.getcwd()}/data'
+        # batch methods: host threads per frame copy between pageable and pinned memory (1 = one numpy copy on the frame thread)
+        self.batch_copy_threads = int(os.environ.get("CRA5_BATCH_COPY_THREADS", "1"))
         self._era5 = None
         if weights is not None:
             self.net = weights.eval().to(self.device)
@@ -327,6 +329,10 @@ class cra5_api:
                 return arr.to(torch.float32)
             arr = arr.numpy()
         pin = net._pinned("api_x_in", tuple(arr.shape), torch.float32)
+        if self.batch_copy_threads > 1 and arr.dtype == np.float32 and arr.flags["C_CONTIGUOUS"]:
+            # a small team per frame (csrc/runtime.hip): chunk c + 1 is memcpy'd while the DMA engine moves chunk c - the
+            # frame is on the device after max(memcpy / team, PCIe) instead of memcpy + PCIe
+            return ops.copy_h2d_staged(net._buf("api_x_dev", tuple(arr.shape)), arr, pin, threads=self.batch_copy_threads)
         # host memcpy (+ dtype conversion) by numpy on THIS thread, GIL released: torch's copy_ fans one 1.11 GB copy out
         # over every core of the box (128 threads: 11 GB/s, one thread: 24 GB/s - tools/api_host_probe.sh) and the
         # twelve frame threads then fight over them; twelve single-threaded copies run side by side
@@ -384,6 +390,9 @@ class cra5_api:
                                                mean=self._mean_flat if denorm else None,
                                                std=self._std_flat if denorm else None)
             pin = self.net._pinned("api_x_out", (C, H, W), torch.float32)
+            if sink is None and out is not None and self.batch_copy_threads > 1:
+                ops.copy_d2h_staged(out[i], x_hat.reshape(C, H, W), pin, threads=self.batch_copy_threads)
+                return out[i]
             pin.copy_(x_hat, non_blocking=True)
             torch.cuda.current_stream().synchronize()
         if sink is not None:

@@ -266,7 +266,30 @@ def host_report():
         pass
     cpus = sorted(own)
     return {"rank": int(os.environ.get("RANK", "0")), "pid": os.getpid(), "n_cpus": len(cpus), "cpus": cpus,
-            "threads": total, "threads_outside_mask": outside, "outside_names": names}
+            "threads": total, "threads_outside_mask": outside, "outside_names": names, "gpu_check": gpu_bind_check()}
+
+
+def gpu_bind_check(local=None):
+    """AFTER the HIP runtime is up: does the PCI address the NUMA bind derived from the KFD topology + the visibility
+    masks (before HIP existed) equal the address HIP reports for the device this rank actually drives?  The KFD node order
+    is assumed to be ROCr's enumeration order and UUID-form visibility lists cannot be resolved from sysfs at all
+    (ADVICE r4): a mismatch or an unresolved case is REPORTED in bench.py's JSON line (`config.host.per_rank[].gpu_check`)
+    instead of being trusted silently.  {"kfd_bdf", "hip_bdf", "match": True | False | None}."""
+    out = {"kfd_bdf": None, "hip_bdf": None, "match": None}
+    try:
+        if not torch.cuda.is_initialized():
+            return out
+        local = torch.cuda.current_device() if local is None else local
+        p = torch.cuda.get_device_properties(local)
+        out["hip_bdf"] = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        phys = _visible_physical_index(local)
+        bdfs = kfd_gpu_bdfs()
+        if phys is not None and phys < len(bdfs):
+            out["kfd_bdf"] = bdfs[phys]
+            out["match"] = out["kfd_bdf"][:-1] == out["hip_bdf"][:-1]        # (function digit aside)
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)
+    return out
 
 
 def gather_objects(obj):

@@ -891,9 +891,9 @@ class VAEformer(nn.Module):
                 # (the residual stream after the last block carries every upstream poison - token-wise, and the global
                 # attention spreads it.  The final LayerNorm's split store is O(gamma * sqrt(D)): a checkpoint with
                 # |gamma| sqrt(D) >= 65 504, or a non-finite mean / std, poisons x_hat BEHIND that probe - a strided
-                # sample of the reconstruction itself (every 257th pixel: a poisoned token's 268 x 110-pixel patch or a bad
-                # channel statistic cannot miss it) is probed as well: ADVICE r4)
-                flag = self._to_host("ok1", self._probe(self._buf(f"t{D}", (self.Hp * self.Wp, D)), (x_hat, 257)))
+                # sample of the reconstruction itself (every 2053rd pixel: ~14 samples of each token's 268 x 110-pixel
+                # patch, ~500 of every channel) is probed as well: ADVICE r4)
+                flag = self._to_host("ok1", self._probe(self._buf(f"t{D}", (self.Hp * self.Wp, D)), (x_hat, 2053)))
             return x_hat, self._finite(flag), None
         return self._range_guard(1, run, "decode")
 
@@ -1105,7 +1105,7 @@ class VAEformer(nn.Module):
                 x_hat = self._decode_frame(y_hat, mean=mean, std=std)
                 flag = self._to_host("ok1", self._probe(self._buf(f"t{self.cfg['embed_dim']}",
                                                                   (self.Hp * self.Wp, self.cfg['embed_dim'])),
-                                                        (x_hat, 257)))
+                                                        (x_hat, 2053)))
             return x_hat, self._finite(flag), None
         return self._range_guard(1, gpu_side, "decompress")
 

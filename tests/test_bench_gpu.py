@@ -15,9 +15,9 @@ def bench_line():
            "--settle-batches", "0", "--roofline-steps", "1", "--no-cpu-baseline", "--api-frames", "12"]
     p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, stdin=subprocess.DEVNULL)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
-    assert len(lines) == 1                       # ONE JSON line on stdout
-    return json.loads(lines[0])
+    out_lines = [l for l in p.stdout.strip().split("\n") if l.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), out_lines[:3]    # ONE JSON line on stdout, nothing else
+    return json.loads(out_lines[0])
 
 
 @pytest.mark.gpu
