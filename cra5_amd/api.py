@@ -140,6 +140,7 @@ class cra5_api:
     def _finite_probe(self, frame):
         """One reduction pass over the frame (ops.probe_sums), asynchronous: NaN / inf anywhere make a partial sum
         non-finite."""
+        self.net._require_gpu()      # (no CPU fallback: the same error every compute entry point raises)
         return self.net._probe(frame, name="api_in")
 
     @staticmethod

@@ -596,15 +596,18 @@ def gaussian_conditional(scales, means, scale_table, y=None, sym_in=None, want=(
     return {k: v for k, v in o.items() if v is not None}
 
 
-def entropy_bottleneck(medians, params, z=None, sym_in=None, want=("sym", "z_hat"), lik_bound=1e-9, shape=None):
-    """z / sym_in: [C, n] (channel-major)."""
+def entropy_bottleneck(medians, params, z=None, sym_in=None, want=("sym", "z_hat"), lik_bound=1e-9, shape=None, sym_out=None):
+    """z / sym_in: [C, n] (channel-major).  sym_out: caller-owned int32 device tensor for the symbols (a slice of a packed
+    device -> host record buffer)."""
     _dev(medians, params, z, sym_in)
     src = z if z is not None else sym_in
     C = medians.numel()
     n_per = src.numel() // C
     dev = src.device
     o = {}
-    o["sym"] = torch.empty(src.shape, device=dev, dtype=torch.int32) if "sym" in want else None
+    o["sym"] = (sym_out.view(src.shape) if sym_out is not None else torch.empty(src.shape, device=dev, dtype=torch.int32)) if "sym" in want else None
+    if sym_out is not None:
+        assert sym_out.dtype == torch.int32 and sym_out.is_contiguous() and sym_out.numel() == src.numel()
     o["z_hat"] = torch.empty(src.shape, device=dev, dtype=torch.float32) if "z_hat" in want else None
     o["lik"] = torch.empty(src.shape, device=dev, dtype=torch.float32) if "lik" in want else None
     assert src.is_contiguous()
@@ -707,17 +710,23 @@ def rans_decode(data, indexes, cdf, cdf_len, offsets, out=None):
     return out
 
 
-def rans_resolve_symbols_compact(symbols, indexes, cdf, cdf_len, offsets):
-    """Device side of the compact resolved encoder -> (start_range int32 [n], rec16 int16 [n], overflow int32 [1])."""
+def rans_resolve_symbols_compact(symbols, indexes, cdf, cdf_len, offsets, out=None):
+    """Device side of the compact resolved encoder -> (start_range int32 [n], rec16 int16 [n], overflow int32 [1]).
+    out: caller-owned (sr, rec, ovf) device tensors of those types (slices of a packed record buffer)."""
     for t in (symbols, indexes, cdf, cdf_len, offsets):
         if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
             raise TypeError("rans_resolve_symbols_compact takes contiguous int32 device tensors")
     n = symbols.numel()
     if indexes.numel() != n:
         raise ValueError("`symbols` and `indexes` should have the same size.")
-    sr = torch.empty(n, device=symbols.device, dtype=torch.int32)
-    rec = torch.empty(n, device=symbols.device, dtype=torch.int16)
-    ovf = torch.empty(1, device=symbols.device, dtype=torch.int32)
+    if out is not None:
+        sr, rec, ovf = out
+        assert sr.dtype == torch.int32 and rec.dtype == torch.int16 and ovf.dtype == torch.int32
+        assert sr.numel() == n and rec.numel() == n and ovf.numel() == 1 and sr.is_contiguous() and rec.is_contiguous()
+    else:
+        sr = torch.empty(n, device=symbols.device, dtype=torch.int32)
+        rec = torch.empty(n, device=symbols.device, dtype=torch.int16)
+        ovf = torch.empty(1, device=symbols.device, dtype=torch.int32)
     check(lib().cra5_rans_resolve_symbols_compact(_p(symbols), _p(indexes), n, _p(cdf), cdf.shape[0], cdf.shape[1],
                                                   _p(cdf_len), _p(offsets), _p(sr), ctypes.c_void_p(rec.data_ptr()),
                                                   _p(ovf), _stream()), "cra5_rans_resolve_symbols_compact")
@@ -757,13 +766,15 @@ def rans_decode_compact(data, indexes_u8, cdf, cdf_len, offsets, out):
     return out
 
 
-def gaussian_conditional_compact(scales, means, scale_table=None, sym16_in=None, want_idx8=False, scale_bound=0.11):
+def gaussian_conditional_compact(scales, means, scale_table=None, sym16_in=None, want_idx8=False, scale_bound=0.11, idx8_out=None):
     """Decode-side halves of gaussian_conditional on compact records: want_idx8 -> uint8 CDF indexes (same shape as
     means); sym16_in (int16 device tensor) -> y_hat = sym + mean (fp32).  Returns {"idx8": ..., "y_hat": ...}."""
     _dev(scales, means, scale_table, sym16_in)
     n = means.numel()
     out = {}
-    idx8 = torch.empty(means.shape, device=means.device, dtype=torch.uint8) if want_idx8 else None
+    idx8 = (idx8_out if idx8_out is not None else torch.empty(means.shape, device=means.device, dtype=torch.uint8)) if want_idx8 else None
+    if idx8_out is not None:
+        assert idx8_out.dtype == torch.uint8 and idx8_out.is_contiguous() and idx8_out.numel() == n
     y_hat = torch.empty(means.shape, device=means.device, dtype=torch.float32) if sym16_in is not None else None
     if sym16_in is not None:
         assert sym16_in.dtype == torch.int16 and sym16_in.is_contiguous() and sym16_in.numel() == n

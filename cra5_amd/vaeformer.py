@@ -374,14 +374,14 @@ class VAEformer(nn.Module):
         finally:
             self._tls.engine_override = prev
 
-    def _probe(self, *items, name="probe"):
+    def _probe(self, *items, name="probe", out=None):
         """Device-side finiteness probe, asynchronous: ops.PROBE_PARTIALS partial sums per argument (a tensor, or (tensor,
         stride) for a strided sample) written by ONE product kernel each into this thread's probe buffer - a sum is
         non-finite as soon as one addend is (fp32 sums of O(1e7) bounded activations do not overflow).  The caller copies
         the values to the host with the phase's other results and tests them there (`_finite`).  (Rounds 1-4 used torch
         reductions + stack / cat here: the last torch compute kernels on the frame path.)"""
         P = ops.PROBE_PARTIALS
-        buf = self._buf(f"{name}{len(items)}", (len(items) * P,))
+        buf = out if out is not None else self._buf(f"{name}{len(items)}", (len(items) * P,))
         for k, it in enumerate(items):
             t, stride = it if isinstance(it, tuple) else (it, 1)
             ops.probe_sums(t if t.is_contiguous() else t.contiguous(), buf[k * P:(k + 1) * P], stride)
@@ -776,11 +776,11 @@ class VAEformer(nn.Module):
         return x_hat
 
     # ---- latent side: everything between y and the entropy coder ---------------------------
-    def _latent_side_frame(self, y, want_lik=False):
+    def _latent_side_frame(self, y, want_lik=False, z_sym_out=None):
         z = self._h_a_frame(y)
         med, pk = self.entropy_bottleneck.device_params()
         eb = ops.entropy_bottleneck(med, pk, z=z, want=("sym", "z_hat") + (("lik",) if want_lik else ()),
-                                    lik_bound=self.entropy_bottleneck.likelihood_bound)
+                                    lik_bound=self.entropy_bottleneck.likelihood_bound, sym_out=z_sym_out)
         scales, means = self._h_s_frame(eb["z_hat"])
         st = self.gaussian_conditional.scale_table
         want = ("idx", "sym", "y_hat") + (("lik",) if want_lik else ())
@@ -864,6 +864,23 @@ class VAEformer(nn.Module):
             b = (key, torch.empty(shape, dtype=dtype, pin_memory=True))
             ws[name] = b
         return b[1]
+
+    def _pack(self, name, fields):
+        """One per-thread device byte buffer holding several typed records back to back (16-byte aligned): the phase's
+        small results travel to the host as ONE copy.  fields: [(key, numel, dtype)] -> (buffer, {key: typed device view},
+        {key: (byte offset, numel, dtype)})."""
+        off, lay = 0, {}
+        for key, n, dt in fields:
+            sz = n * torch.empty((), dtype=dt).element_size()
+            lay[key] = (off, n, dt)
+            off = (off + sz + 15) // 16 * 16
+        buf = self._buf(name, (off,), torch.uint8)
+        views = {k: buf[o:o + n * torch.empty((), dtype=dt).element_size()].view(dt) for k, (o, n, dt) in lay.items()}
+        return buf, views, lay
+
+    @staticmethod
+    def _unpack(host_buf, lay):
+        return {k: host_buf[o:o + n * torch.empty((), dtype=dt).element_size()].view(dt) for k, (o, n, dt) in lay.items()}
 
     def _to_host(self, name, t):
         h = self._pinned(name, t.shape, t.dtype)
@@ -952,33 +969,42 @@ class VAEformer(nn.Module):
         self.gaussian_conditional._check()
         gc = self.gaussian_conditional
 
+        P = ops.PROBE_PARTIALS
+
         def gpu_side():
             with self._gpu_phase(prio=0):
                 yy = y if y is not None else self._encode_y_frame(x, mean=mean, std=std)
-                s = self._latent_side_frame(yy.contiguous())
-                par = self._hs_parent(s["scales"], s["means"])
-                pr = self._probe(yy, *par)          # [y | mu, sigma]: PROBE_PARTIALS values each
-                z_sym = self._to_host("z_sym", s["z_sym"])
                 if self.resolve_on_gpu and self.compact_records:
-                    # symbol -> (start | range, 16-bit escape record) against the CDF tables on the device:
-                    # the host coder is a pure state-update loop, and 6 instead of 9 bytes per latent cross PCIe
-                    sr, rec, ovf = ops.rans_resolve_symbols_compact(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
-                                                                    gc._quantized_cdf, gc._cdf_length, gc._offset)
-                    host = ("compact", self._to_host("y_sr", sr), self._to_host("y_rec", rec), None)
-                    keep["sym"], keep["idx"], keep["ovf"] = s["y_sym"], s["idx"], ovf   # for the (rare) 32-bit re-resolve
-                elif self.resolve_on_gpu:
-                    sr, raw, esc = ops.rans_resolve_symbols(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
-                                                            gc._quantized_cdf, gc._cdf_length, gc._offset)
-                    host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
+                    # Everything the host phase needs leaves the device as ONE copy (round 5; rounds 1-4: five): the z
+                    # symbols, the y records - symbol -> (start | range, 16-bit escape record) resolved against the CDF
+                    # tables on the device (the host coder is a pure state-update loop, 6 instead of 9 bytes
+                    # per latent cross PCIe) - their overflow word and the finiteness probes of y and of mu / sigma are
+                    # written by their kernels into slices of one per-thread record buffer.
+                    nz, nl = self.entropy_bottleneck.channels * self.Hz * self.Wz, yy.numel()
+                    buf, v, lay = self._pack("enc_pack", [("z_sym", nz, torch.int32), ("sr", nl, torch.int32),
+                                                           ("rec", nl, torch.int16), ("ovf", 1, torch.int32),
+                                                           ("probe", 3 * P, torch.float32)])
+                    s = self._latent_side_frame(yy.contiguous(), z_sym_out=v["z_sym"])
+                    par = self._hs_parent(s["scales"], s["means"])
+                    self._probe(yy, *par, out=v["probe"][:(1 + len(par)) * P])
+                    ops.rans_resolve_symbols_compact(s["y_sym"].reshape(-1), s["idx"].reshape(-1), gc._quantized_cdf,
+                                                     gc._cdf_length, gc._offset, out=(v["sr"], v["rec"], v["ovf"]))
+                    keep["sym"], keep["idx"] = s["y_sym"], s["idx"]   # for the (rare) 32-bit re-resolve
+                    h = self._unpack(self._to_host("enc_pack", buf), lay)
+                    fl = h["probe"][:(1 + len(par)) * P]
+                    z_sym, host = h["z_sym"].view(tuple(s["z_sym"].shape)), ("compact", h["sr"], h["rec"], h["ovf"])
                 else:
-                    host = ("plain", self._to_host("y_sym", s["y_sym"]), self._to_host("idx", s["idx"]))
-                # the phase's small results: the finiteness probes of y and of mu / sigma in one copy, the compact
-                # records' overflow word in another (no torch cat / cast kernels on the frame path)
-                fl = self._to_host("enc_flags", pr)
-                ovf_h = self._to_host("enc_ovf", keep["ovf"]) if "ovf" in keep else None
-            if host[0] == "compact":
-                host = host[:3] + (ovf_h,)
-            P = ops.PROBE_PARTIALS
+                    s = self._latent_side_frame(yy.contiguous())
+                    par = self._hs_parent(s["scales"], s["means"])
+                    pr = self._probe(yy, *par)          # [y | mu, sigma]: PROBE_PARTIALS values each
+                    z_sym = self._to_host("z_sym", s["z_sym"])
+                    if self.resolve_on_gpu:
+                        sr, raw, esc = ops.rans_resolve_symbols(s["y_sym"].reshape(-1), s["idx"].reshape(-1),
+                                                                gc._quantized_cdf, gc._cdf_length, gc._offset)
+                        host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
+                    else:
+                        host = ("plain", self._to_host("y_sym", s["y_sym"]), self._to_host("idx", s["idx"]))
+                    fl = self._to_host("enc_flags", pr)
             return (z_sym, host), self._finite(fl[:P]), self._finite(fl[P:])   # (the phase ended with a stream sync)
         keep = {}
         z_sym, host = self._range_guard(0, gpu_side, "compress")
@@ -1061,17 +1087,24 @@ class VAEformer(nn.Module):
             scales, means = self._h_s_frame(z_hat)
             scales, means = scales.contiguous(), means.contiguous()
             compact = self.compact_records and gc.scale_table.numel() <= 256
+            par = self._hs_parent(scales, means)
             if compact:
                 # compact records (round 4): uint8 CDF indexes to the host, int16 symbols back - 8 instead of 21 MB of
-                # PCIe traffic on the decode side's latency path
-                idx = ops.gaussian_conditional_compact(scales, means, gc.scale_table, want_idx8=True,
-                                                       scale_bound=self._scale_bound())["idx8"]
+                # PCIe traffic on the decode side's latency path; the indexes and the finiteness probes of mu / sigma
+                # leave as ONE copy (round 5)
+                P = ops.PROBE_PARTIALS
+                buf, v, lay = self._pack("dec_pack", [("idx8", means.numel(), torch.uint8), ("probe", 2 * P, torch.float32)])
+                ops.gaussian_conditional_compact(scales, means, gc.scale_table, want_idx8=True,
+                                                 scale_bound=self._scale_bound(), idx8_out=v["idx8"])
+                self._probe(*par, out=v["probe"][:len(par) * P])
+                h = self._unpack(self._to_host("dec_pack", buf), lay)
+                idx_h, ok_h = h["idx8"], h["probe"][:len(par) * P]
             else:
                 idx = ops.gaussian_conditional(scales, means, gc.scale_table,
                                                sym_in=torch.zeros_like(means, dtype=torch.int32), want=("idx",),
                                                scale_bound=self._scale_bound())["idx"]
-            idx_h = self._to_host("idx8" if compact else "idx", idx)
-            ok_h = self._to_host("ok_h", self._probe(*self._hs_parent(scales, means)))
+                idx_h = self._to_host("idx", idx)
+                ok_h = self._to_host("ok_h", self._probe(*par))
         if not self._finite(ok_h):
             raise FloatingPointError("decompress: the hyper-prior path produced non-finite entropy parameters (pinned "
                                      "engine, no fallback): the stream does not belong to this checkpoint, or the "
