@@ -47,7 +47,7 @@ SIGNATURES = {
                                    c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cra5_split_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "cra5_layernorm_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
-                                   c_int, c_float, c_void_p]),
+                                   c_int, c_float, c_int, c_void_p]),
     "cra5_window_attention_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_float, c_void_p]),
     "cra5_window_attention_split": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

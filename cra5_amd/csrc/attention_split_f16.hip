@@ -107,14 +107,19 @@ __host__ __device__ __forceinline__ int bal_piece_of(long S, int G, long s) {
 }
 constexpr int WS_ROW = 68;   // floats per query of a partial: O[64], m, l, 2 pad (16-byte rows)
 
-template <int NW, bool HI, bool GLOBAL, bool BAL = false>
+// PLAIN (reduced-precision mode only, round 5): qkv rows, the pad row and the out_s rows are PLAIN f16 - element n at
+// half n of the row (row pitch unchanged: a plain row is the first half of a split row) - as the plain-output qkv GEMM
+// writes them and the plain-operand proj GEMM reads them: K / V tiles are staged as 128-byte instead of 256-byte rows.
+template <int NW, bool HI, bool GLOBAL, bool BAL = false, bool PLAIN = false>
 __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void window_attention_split_kernel(
     const unsigned short *__restrict__ qkv, long ldq /* halves per row = 2*Kp */,
     const unsigned short *__restrict__ pad_row, float *__restrict__ out, unsigned short *__restrict__ out_s,
     int Kp_out, int C, int heads, WinGeom g, int q_tiles, float scale, BalArgs bal) {
   static_assert(!BAL || GLOBAL, "the balanced schedule is for whole-grid launches");
+  static_assert(!PLAIN || HI, "plain rows carry no lo plane");
   constexpr int NT = NW * 64;
-  constexpr int PIECES = 32 * 16;                 // 16-byte pieces per K (or V) tile
+  constexpr int PPR = PLAIN ? 8 : 16;             // 16-byte pieces per K (or V) row of one head: 64 d x (hi | hi + lo)
+  constexpr int PIECES = 32 * PPR;                // 16-byte pieces per K (or V) tile
   constexpr int STG = (PIECES + NT - 1) / NT;
 
   // [K hi][K lo] : 32 x KS ;  [V hi][V lo] : 32 x VS (row-major like K, transposed by the READ)
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   const int l31 = lane & 31, h = lane >> 5;
   const int hoff = head * HD;
   // halves offset of this head's q / k / v slice inside a split row (64 d = 2 chunks = 128 halves)
-  const long qoff = 2L * hoff, koff = 2L * (C + hoff), voff = 2L * (2 * C + hoff);
+  const long qoff = (PLAIN ? 1L : 2L) * hoff, koff = (PLAIN ? 1L : 2L) * (C + hoff), voff = (PLAIN ? 1L : 2L) * (2 * C + hoff);
 
   if (!GLOBAL) {
     const long long pad_delta = reinterpret_cast<const char *>(pad_row) - reinterpret_cast<const char *>(qkv);
@@ -215,8 +220,13 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int chunk = s >> 1, pp = 2 * (s & 1) + h;
-      qh[s] = *reinterpret_cast<const half8 *>(qrow + chunk * 64 + pp * 8);
-      ql[s] = *reinterpret_cast<const half8 *>(qrow + chunk * 64 + 32 + pp * 8);
+      if (PLAIN) {
+        qh[s] = *reinterpret_cast<const half8 *>(qrow + 16 * s + 8 * h);
+        ql[s] = qh[s];   // (never used: HI)
+      } else {
+        qh[s] = *reinterpret_cast<const half8 *>(qrow + chunk * 64 + pp * 8);
+        ql[s] = *reinterpret_cast<const half8 *>(qrow + chunk * 64 + 32 + pp * 8);
+      }
     }
   }
   const float cexp = scale * 1.44269504088896340736f;  // scores -> log2 domain
@@ -237,9 +247,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   constexpr bool TWO = STG == 2;
   // thread -> (row, piece) of its two K pieces and (row, two pieces) of V; indexes past the tile
   // (NW = 6: 384 threads x 2 > 512 pieces) are clamped: loaded redundantly, never stored.
-  const int krow0 = min(tid >> 4, 31), krow1 = min((tid + NT) >> 4, 31);
-  const long kcol = koff + (tid & 15) * 8;                                  // halves
-  const long vcol = voff + (tid & 15) * 8;
+  const int krow0 = min(tid / PPR, 31), krow1 = min((tid + NT) / PPR, 31);
+  const long kcol = koff + (tid % PPR) * 8;                                 // halves
+  const long vcol = voff + (tid % PPR) * 8;
   // whole-grid launches walk three running row pointers (+32 rows per tile); windowed ones look
   // the rows up in the table.
   const unsigned short *kq0 = qkv + (size_t)(krow0 + 32 * j0) * ldq + kcol;
@@ -286,8 +296,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   {                                                                                       \
     const int idx = tid + (P)*NT;                                                         \
     if (idx < PIECES) {                                                                   \
-      const int row = idx >> 4, piece = idx & 15;                                         \
-      const int plane = (piece >> 2) & 1, d0 = 32 * (piece >> 3) + 8 * (piece & 3);       \
+      const int row = idx / PPR, piece = idx % PPR;                                       \
+      const int plane = PLAIN ? 0 : (piece >> 2) & 1, d0 = PLAIN ? 8 * piece : 32 * (piece >> 3) + 8 * (piece & 3); \
       *reinterpret_cast<uint4 *>(Ks + (BUF)*KBUF + plane * KPL + row * KS + d0) = sk##P;  \
     }                                                                                     \
   }
@@ -296,8 +306,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   {                                                                                       \
     const int idx = tid + (P)*NT;                                                         \
     if (idx < PIECES) {                                                                   \
-      const int row = idx >> 4, piece = idx & 15;                                         \
-      const int plane = (piece >> 2) & 1, d0 = 32 * (piece >> 3) + 8 * (piece & 3);       \
+      const int row = idx / PPR, piece = idx % PPR;                                       \
+      const int plane = PLAIN ? 0 : (piece >> 2) & 1, d0 = PLAIN ? 8 * piece : 32 * (piece >> 3) + 8 * (piece & 3); \
       *reinterpret_cast<uint4 *>(Vt + (BUF)*VBUF + plane * VPL + row * VS + d0) = sv##P;  \
     }                                                                                     \
   }
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
 #endif
           if (srow) {
             const int c0 = hoff + 32 * t + 16 * pr + 8 * h;          // first of this lane's 8 columns after the swap
-            unsigned short *sp = srow + (c0 >> 5) * 64 + (c0 & 31);
+            unsigned short *sp = srow + (PLAIN ? c0 : (c0 >> 5) * 64 + (c0 & 31));
             *reinterpret_cast<uint4 *>(sp) = make_uint4(ha0, ha1, hb0, hb1);
             // (reduced-precision mode: the proj GEMM reads the hi plane only)
             if (!HI) *reinterpret_cast<uint4 *>(sp + 32) = make_uint4(la0, la1, lb0, lb1);
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
 // 8; piece p of the group contributes exp2(m_p - M) (O_p, l_p), summed in piece order (fixed association: deterministic).
 __global__ __launch_bounds__(256) void attention_merge_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                               unsigned short *__restrict__ out_s, int Kp_out, int C,
-                                                              BalArgs bal, int nw) {
+                                                              BalArgs bal, int nw, int plain) {
   const int t = blockIdx.x % nw, hg = blockIdx.x / nw;
   const int grp = hg % bal.n_grp, head = hg / bal.n_grp;
   if (grp * nw + t >= bal.rem) return;                        // the last group may be partial
@@ -632,8 +642,13 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float *__res
   }
   if (out_s) {
     unsigned short *srow = out_s + (size_t)tok * 2 * Kp_out;
-    cra5_store_split4(srow, col, acc[0], acc[1], acc[2], acc[3]);
-    cra5_store_split4(srow, col + 4, acc[4], acc[5], acc[6], acc[7]);
+    if (plain) {
+      cra5_store_plain4(srow, col, acc[0], acc[1], acc[2], acc[3]);
+      cra5_store_plain4(srow, col + 4, acc[4], acc[5], acc[6], acc[7]);
+    } else {
+      cra5_store_split4(srow, col, acc[0], acc[1], acc[2], acc[3]);
+      cra5_store_split4(srow, col + 4, acc[4], acc[5], acc[6], acc[7]);
+    }
   }
 }
 
@@ -684,7 +699,7 @@ size_t balanced_ws_bytes(const BalArgs &b, int heads) {
   return (size_t)heads * b.n_grp * b.maxp * NW_GLOBAL * 32 * WS_ROW * sizeof(float);
 }
 
-template <bool HI>
+template <bool HI, bool PLAIN = false>
 int launch_balanced(const unsigned short *qkv, long ldq, const unsigned short *pad_row, float *out, unsigned short *out_s,
                     int Kp_out, int C, int heads, int H, int W, float scale, BalArgs b, float *ws, hipStream_t st) {
   WinGeom g;
@@ -695,16 +710,16 @@ int launch_balanced(const unsigned short *qkv, long ldq, const unsigned short *p
   g.nwc = 1;
   b.ws = ws;
   const int n_pass = b.n_full + (b.rem ? 1 : 0);
-  hipLaunchKernelGGL((window_attention_split_kernel<NW_GLOBAL, HI, true, true>), dim3(n_pass * b.n_wg_pass),
+  hipLaunchKernelGGL((window_attention_split_kernel<NW_GLOBAL, HI, true, true, PLAIN>), dim3(n_pass * b.n_wg_pass),
                      dim3(NW_GLOBAL * 64), 0, st, qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, 0, scale, b);
   int rc = (int)hipGetLastError();
   if (rc || b.rem == 0) return rc;
   hipLaunchKernelGGL(attention_merge_kernel, dim3(heads * b.n_grp * NW_GLOBAL), dim3(256), 0, st, ws, out, out_s, Kp_out,
-                     C, b, NW_GLOBAL);
+                     C, b, NW_GLOBAL, PLAIN ? 1 : 0);
   return (int)hipGetLastError();
 }
 
-template <int NW, bool HI, bool GLOBAL>
+template <int NW, bool HI, bool GLOBAL, bool PLAIN = false>
 int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, float *out, unsigned short *out_s,
            int Kp_out, int C, int heads, int H, int W, int wh, int ww, float scale, hipStream_t st) {
   WinGeom g;
@@ -716,7 +731,7 @@ int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, f
   g.nwc = (W + ww - 1) / ww;
   const int L = wh * ww;
   const int q_tiles = (L + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL((window_attention_split_kernel<NW, HI, GLOBAL>), dim3(q_tiles * nwr * g.nwc * heads), dim3(NW * 64), 0, st,
+  hipLaunchKernelGGL((window_attention_split_kernel<NW, HI, GLOBAL, false, PLAIN>), dim3(q_tiles * nwr * g.nwc * heads), dim3(NW * 64), 0, st,
                      qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, q_tiles, scale, BalArgs{});
   return (int)hipGetLastError();
 }
@@ -734,6 +749,10 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   if (((uintptr_t)qkv_split & 15) || ((uintptr_t)pad_row_split & 15)) return CRA5_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int L = wh * ww;
+  // hi_only: 0 = fp32-accurate, 1 = reduced precision on split rows, 3 = reduced precision on PLAIN f16 rows (qkv, the
+  // pad row and out_split: element n at half n; row pitches unchanged)
+  if (hi_only != 0 && hi_only != 1 && hi_only != 3) return CRA5_ERR_ARG;
+  const bool plain = hi_only == 3;
   const long ldq = 2L * qkv_kp;
   const bool whole = (wh == H && ww == W);
   if (!whole && L > MAX_WIN_TOKENS) return CRA5_ERR_ARG;   // attention_f32.hip covers those
@@ -746,10 +765,13 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
         (balanced_ws_bytes(b, heads) == 0 ||
          (workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= balanced_ws_bytes(b, heads)))) {
       float *ws = reinterpret_cast<float *>(workspace);
+      if (plain)
+        return launch_balanced<true, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, scale, b, ws, st);
       if (hi_only)
         return launch_balanced<true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, scale, b, ws, st);
       return launch_balanced<false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, scale, b, ws, st);
     }
+    if (plain) return launch<NW_GLOBAL, true, true, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
     if (hi_only) CRA5_ATT_GO(NW_GLOBAL, true, true);
     CRA5_ATT_GO(NW_GLOBAL, false, true);
   }
@@ -757,6 +779,7 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   // window, K / V staged three times instead of five) looks better on paper and ran with ONE work-group per CU: its
   // waves land on the SIMDs 2-2-1-1, a second work-group would put four 156-register waves on one SIMD (3 fit), so
   // 864 work-groups took 3.4 rounds instead of 1.7.  Four waves are one per SIMD: three work-groups always fit.
+  if (plain) return launch<4, true, false, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
   if (hi_only) CRA5_ATT_GO(4, true, false);
   CRA5_ATT_GO(4, false, false);
 #undef CRA5_ATT_GO

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float *__restrict__ y,
                                                         int ldy, unsigned short *__restrict__ ys, int Kp, int rows,
-                                                        int D, float eps) {
+                                                        int D, float eps, int ys_plain) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -75,11 +75,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (y) *reinterpret_cast<float4 *>(yr + c) = o;
-      if (ys) cra5_store_split4(ys + (size_t)row * 2 * Kp, c, o.x, o.y, o.z, o.w);
+      if (ys) {   // (row pitch 2 * Kp halves either way: a plain row is the first half of a split row)
+        if (ys_plain) cra5_store_plain4(ys + (size_t)row * 2 * Kp, c, o.x, o.y, o.z, o.w);
+        else cra5_store_split4(ys + (size_t)row * 2 * Kp, c, o.x, o.y, o.z, o.w);
+      }
     }
   }
   if (ys)  // zero the K padding of the split row (D..Kp)
-    for (int c = D + lane; c < Kp; c += 64) cra5_store_split(ys + (size_t)row * 2 * Kp, c, 0.f);
+    for (int c = D + lane; c < Kp; c += 64) {
+      if (ys_plain) cra5_store_plain(ys + (size_t)row * 2 * Kp, c, 0.f);
+      else cra5_store_split(ys + (size_t)row * 2 * Kp, c, 0.f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -689,14 +695,14 @@ inline int grid_for(size_t n, int block = 256) {
 extern "C" {
 
 int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float *beta, float *y, int ldy,
-                       uint16_t *y_split, int split_kp, int rows, int D, float eps, void *stream) {
+                       uint16_t *y_split, int split_kp, int rows, int D, float eps, int split_plain, void *stream) {
   if (!x || !gamma || !beta || (!y && !y_split) || rows <= 0 || D <= 0 || (D & 3) || (ldx & 3) || D > 2048)
     return CRA5_ERR_ARG;
   if (y && (ldy & 3)) return CRA5_ERR_ARG;
   if (y_split && (split_kp < D || split_kp % 32)) return CRA5_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4), block(256);
-#define CRA5_LN(V) hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, y_split, split_kp, rows, D, eps)
+#define CRA5_LN(V) hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, st, x, ldx, gamma, beta, y, ldy, y_split, split_kp, rows, D, eps, split_plain)
   if (D <= 256) CRA5_LN(1);
   else if (D <= 512) CRA5_LN(2);
   else if (D <= 1024) CRA5_LN(4);

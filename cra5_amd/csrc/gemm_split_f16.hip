@@ -156,6 +156,15 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // MFMAs per accumulator and 16-wide k-block instead of three, and K advances twice as fast.
   constexpr int KSTEP = (NPROD == 2) ? 2 * BK : BK;
   const int nk_all = Kp / KSTEP;
+  // ... and (round 5) an operand of that form may be a PLAIN f16 matrix (CRA5_GEMM_A_PLAIN / _W_PLAIN): a row is Kp
+  // contiguous halves, so a 64-wide k-step of a row is ONE full 128-byte line instead of the hi halves of two split
+  // chunks (two half-lines).  An LDS-DMA instruction then asks for 8 lines instead of 16 half-lines, which is what the
+  // wide form's read phase pays for: -13..-18 % per launch (profiles/r05_f16_plain_layout_experiment.txt).  Same LDS
+  // image, same fragment reads, same arithmetic - bit-identical results.  CRA5_GEMM_OUT_PLAIN: C_split row = N
+  // contiguous halves (the layout the next reduced-precision GEMM / the attention kernel reads).
+  const bool a_plain = (NPROD == 2) && (flags & CRA5_GEMM_A_PLAIN);
+  const bool w_plain = (NPROD == 2) && (flags & CRA5_GEMM_W_PLAIN);
+  const bool o_plain = (NPROD != 3) && (flags & CRA5_GEMM_OUT_PLAIN);
 
   const int tile = pid, ka = 0, kb = nk_all;
   // Tile order: the 32 work-groups an XCD runs at a time own 32 CONSECUTIVE tile numbers (xcd_remap), so tiles are
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
       const int lpiece = (NPROD >= 2) ? ((lane & 7) ^ ((row_ >> 1) & 7)) : ((lane & 3) ^ ((row_ >> 2) & 3));
       // halves offset of the logical piece inside the row: contiguous [hi | lo] of one chunk, or (NPROD == 2) the hi
       // half of chunk 0 (pieces 0-3) and of chunk 1 (pieces 4-7)
-      const int poffs = (NPROD == 2) ? ((lpiece >> 2) * 64 + (lpiece & 3) * 8) : lpiece * 8;
+      const int poffs = (NPROD == 2 && !(isA ? a_plain : w_plain)) ? ((lpiece >> 2) * 64 + (lpiece & 3) * 8) : lpiece * 8;
       if (isA)
         src[q] = A + (size_t)min(m0 + row_, M - 1) * lda + poffs + (size_t)ka * 64;
       else
@@ -238,6 +247,7 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
 #define CRA5_GLDS16(SRC, DST) (void)(SRC)
 #endif
 #define CRA5_DMA_KSTRIDE (2 * KSTEP * 2)   /* bytes along a row per k-step: 128 B per 32-wide chunk (hi + lo) */
+  const unsigned kstride_a = a_plain ? 128u : (unsigned)CRA5_DMA_KSTRIDE, kstride_w = w_plain ? 128u : (unsigned)CRA5_DMA_KSTRIDE;
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_STAGE_LOAD(BUF)                                                                   \
   {                                                                                            \
@@ -249,8 +259,8 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"          \
                      :: "s"(dst_), "v"(soff[q]), "s"((q * NWAVE * 8 < BM) ? curA : curW) : "memory", "m0"); \
       }                                                                                        \
-      curA += CRA5_DMA_KSTRIDE;                                                                \
-      curW += CRA5_DMA_KSTRIDE;                                                                \
+      curA += kstride_a;                                                                       \
+      curW += kstride_w;                                                                       \
     } else {                                                                                   \
       _Pragma("unroll") for (int q = 0; q < IPW; ++q) {                                        \
         if (GROUPS % NWAVE == 0 || wave + q * NWAVE < GROUPS)                                  \
@@ -562,6 +572,9 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
     return e ? atoi(e) : 0;
   }();
   const bool longk = Kp > 8192;
+  // plain-f16 operands / output exist in the wide reduced-precision form only (the caller falls back to split rows)
+  constexpr int PLAIN_ANY = CRA5_GEMM_A_PLAIN | CRA5_GEMM_W_PLAIN | CRA5_GEMM_OUT_PLAIN;
+  if ((flags & PLAIN_ANY) && (!(flags & CRA5_GEMM_HI_ONLY) || longk || tiles128 < 256 || (Kp % 64))) return CRA5_ERR_ARG;
   if (longk) CRA5_GO(2, 2, 2, 2, true);
   if (flags & CRA5_GEMM_HI_ONLY) {   // reduced precision: one f16 MFMA per product
     const bool wide = (M >= 1024 && N >= 2048);
@@ -606,7 +619,10 @@ extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t 
   if ((flags & CRA5_EPI_RES) && !res) return CRA5_ERR_ARG;
   if (C_split && (ldc_split_kp % 32 || ldc_split_kp < N)) return CRA5_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const long lda = 2L * lda_kp, ldw = 2L * ldw_kp, ldcs = 2L * ldc_split_kp;
+  // row pitches in halves: a split row holds 2 halves per k, a plain row one (the caller states its pitch in halves)
+  const bool a_plain = flags & CRA5_GEMM_A_PLAIN, w_plain = flags & CRA5_GEMM_W_PLAIN, o_plain = flags & CRA5_GEMM_OUT_PLAIN;
+  const long lda = a_plain ? (long)lda_kp : 2L * lda_kp, ldw = w_plain ? (long)ldw_kp : 2L * ldw_kp;
+  const long ldcs = o_plain ? (long)ldc_split_kp : 2L * ldc_split_kp;
   // Long reductions (patch-embed conv, K = 29 480): K is cut into chunks of <= 8192 whose
   // partial products are chained through the fp32 C matrix (C += A_i . W_i): a two-level
   // sum (each chunk accumulates in the MFMA accumulators, chunks add in fp32) without a
@@ -617,8 +633,8 @@ extern "C" int cra5_gemm_nt_split(const uint16_t *A, int lda_kp, const uint16_t 
     const int per = ((Kp / gran + nchunk - 1) / nchunk) * gran;
     for (int k0 = 0, i = 0; k0 < Kp; k0 += per, ++i) {
       const int kc = (Kp - k0 < per) ? Kp - k0 : per;
-      const int f = ((i == 0) ? flags : CRA5_EPI_RES) | (flags & CRA5_GEMM_HI_ONLY);
-      const int rc = gemm_dispatch(A + 2L * k0, lda, W + 2L * k0, ldw, C, ldc, nullptr, 0, (i == 0) ? bias : nullptr,
+      const int f = ((i == 0) ? flags : CRA5_EPI_RES) | (flags & (CRA5_GEMM_HI_ONLY | CRA5_GEMM_A_PLAIN | CRA5_GEMM_W_PLAIN));
+      const int rc = gemm_dispatch(A + (a_plain ? 1L : 2L) * k0, lda, W + (w_plain ? 1L : 2L) * k0, ldw, C, ldc, nullptr, 0, (i == 0) ? bias : nullptr,
                                    (i == 0) ? res : C, (i == 0) ? ldr : ldc, M, N, kc, wscale_inv, f, st);
       if (rc) return rc;
     }
@@ -674,11 +690,15 @@ extern "C" int cra5_gemm_nt_split_unembed(const uint16_t *A, int lda_kp, const u
   ue.W = W;
   ue.Hp = Hp;
   ue.Wp = Wp;
-  const long lda = 2L * lda_kp, ldw = 2L * ldw_kp;
+  // hi_only: 0 = fp32-accurate; 1 = reduced precision on split operands; | 2: A is a plain f16 matrix, | 4: Wt is
+  // (pitches then in halves, as for cra5_gemm_nt_split's CRA5_GEMM_A_PLAIN / _W_PLAIN)
+  const bool a_plain = hi_only & 2, w_plain = hi_only & 4;
+  if ((a_plain || w_plain) && (!(hi_only & 1) || (Kp % 64))) return CRA5_ERR_ARG;
+  const long lda = a_plain ? (long)lda_kp : 2L * lda_kp, ldw = w_plain ? (long)ldw_kp : 2L * ldw_kp;
   int rc;
   if (hi_only && Kp % 64 == 0)
     rc = launch<2, 4, 4, 2, false, 2, 2, true>(A, lda, Wt, ldw, x, 0, nullptr, 0, nullptr, nullptr, 0, M, N, Kp, wscale_inv,
-                                               CRA5_GEMM_HI_ONLY, st, ue);
+                                               CRA5_GEMM_HI_ONLY | (a_plain ? CRA5_GEMM_A_PLAIN : 0) | (w_plain ? CRA5_GEMM_W_PLAIN : 0), st, ue);
   else if (hi_only)
     rc = launch<2, 4, 4, 2, false, 2, 1, true>(A, lda, Wt, ldw, x, 0, nullptr, 0, nullptr, nullptr, 0, M, N, Kp, wscale_inv,
                                                CRA5_GEMM_HI_ONLY, st, ue);

@@ -91,3 +91,17 @@ __device__ __forceinline__ void cra5_store_split4(unsigned short *row, int n, fl
   *reinterpret_cast<uint2 *>(p) = make_uint2(h01, h23);
   *reinterpret_cast<uint2 *>(p + 32) = make_uint2(l01, l23);
 }
+
+// PLAIN f16 rows (reduced-precision mode, round 5): element n of a row is the half at offset n - the same hi value the
+// split layout stores, no lo plane.  Four consecutive columns (n % 4 == 0): one 8-byte store.
+__device__ __forceinline__ void cra5_store_plain4(unsigned short *row, int n, float a, float b, float c, float d) {
+  unsigned h01, l01, h23, l23;
+  cra5_split_pair(a, b, h01, l01);   // (the lo halves are dead code here; the range probe of the rangecheck flavour stays)
+  cra5_split_pair(c, d, h23, l23);
+  *reinterpret_cast<uint2 *>(row + n) = make_uint2(h01, h23);
+}
+__device__ __forceinline__ void cra5_store_plain(unsigned short *row, int n, float v) {
+  _Float16 hi, lo;
+  cra5_split(v, hi, lo);
+  row[n] = __builtin_bit_cast(unsigned short, hi);
+}

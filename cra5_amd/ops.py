@@ -206,10 +206,25 @@ class SplitMat:
     uint16 tensor [rows, 2*Kp] (128-byte chunks of 32 hi | 32 lo halves), Kp = K rounded up to
     32 (zero padded), value = (hi + lo) * scale_inv."""
 
-    __slots__ = ("data", "rows", "K", "Kp", "scale_inv")
+    __slots__ = ("data", "rows", "K", "Kp", "scale_inv", "plain")
 
-    def __init__(self, data, rows, K, Kp, scale_inv=1.0):
+    def __init__(self, data, rows, K, Kp, scale_inv=1.0, plain=False):
         self.data, self.rows, self.K, self.Kp, self.scale_inv = data, rows, K, Kp, scale_inv
+        # plain = True (reduced-precision mode, round 5): the rows hold PLAIN f16 - element n at half n, no lo plane; the
+        # row pitch is data.shape[1] halves (2 * Kp when the plain row sits in the first half of a split-layout buffer, Kp
+        # for a plain weight copy).  Set by the producer of each call.
+        self.plain = plain
+
+    @property
+    def pitch(self):
+        """what the C ABI takes as lda_kp / ldw_kp / ldc_split_kp: k-elements per split row, halves per plain row"""
+        return self.data.shape[1] if self.plain else self.Kp
+
+    def plain_copy(self):
+        """A PLAIN f16 copy of this (weight) matrix: its hi plane, [rows, Kp] contiguous, same scale."""
+        assert not self.plain
+        hi = self.data.view(self.rows, self.Kp // 32, 2, 32)[:, :, 0].reshape(self.rows, self.Kp).contiguous()
+        return SplitMat(hi, self.rows, self.K, self.Kp, self.scale_inv, plain=True)
 
     @staticmethod
     def empty(rows, K, device, zero=False):
@@ -220,6 +235,8 @@ class SplitMat:
 
     def to_float(self):
         """Reconstruct the fp32 values (tests / debugging)."""
+        if self.plain:
+            return self.data.view(torch.float16)[:, : self.K].float() * self.scale_inv
         h = self.data.view(torch.float16).view(self.rows, self.Kp // 32, 2, 32).float()
         return ((h[:, :, 0] + h[:, :, 1]).reshape(self.rows, self.Kp)[:, : self.K]) * self.scale_inv
 
@@ -248,12 +265,24 @@ def split_f16(x, scale_pow2=None, out=None):
     check(lib().cra5_split_f16(_p(x), _row_stride(x), _p(out.data), rows, K, out.Kp, scale, _stream()),
           "cra5_split_f16")
     out.scale_inv = 1.0 / scale
+    out.plain = False
     return out
 
 
-def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True, hi_only=False):
+GEMM_A_PLAIN, GEMM_W_PLAIN, GEMM_OUT_PLAIN = 16, 32, 64
+
+
+def plain_ok(M, N, Kp):
+    """Shapes on which cra5_gemm_nt_split takes plain-f16 operands / writes a plain output (the wide reduced-precision
+    form: big tiles, 64-wide k-steps, no long-K chain through a split output)."""
+    return ((M + 127) // 128) * ((N + 127) // 128) >= 256 and Kp % 64 == 0
+
+
+def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=None, want_f32=True, hi_only=False,
+                  out_plain=False):
     """epi(a @ w^T) with a, w SplitMat (same K).  out: fp32 [M, N] (row-strided ok) unless
-    want_f32=False; out_split: SplitMat [M, N] to receive the split-f16 result."""
+    want_f32=False; out_split: SplitMat [M, N] to receive the split-f16 result.  Reduced-precision mode (hi_only): a / w
+    may be PLAIN matrices (SplitMat.plain) and out_plain=True writes out_split's rows plain."""
     _devs(a.data, w.data)
     _dev(bias, res, out)
     M, N = a.rows, w.rows
@@ -266,11 +295,16 @@ def gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_split=Non
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
     if hi_only:
         flags |= GEMM_HI_ONLY
+    if a.plain or w.plain or out_plain:
+        assert hi_only, "plain-f16 operands exist in the reduced-precision mode only"
+        flags |= (GEMM_A_PLAIN if a.plain else 0) | (GEMM_W_PLAIN if w.plain else 0) | (GEMM_OUT_PLAIN if out_plain else 0)
+    if out_split is not None:
+        out_split.plain = bool(out_plain)
     ev = TIMER.start() if TIMER is not None else None
-    check(lib().cra5_gemm_nt_split(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
+    check(lib().cra5_gemm_nt_split(_p(a.data), a.pitch, _p(w.data), w.pitch, _p(out),
                                    _row_stride(out) if out is not None else 0,
                                    _p(out_split.data) if out_split is not None else None,
-                                   out_split.Kp if out_split is not None else 0, _p(bias), _p(res),
+                                   out_split.pitch if out_split is not None else 0, _p(bias), _p(res),
                                    _row_stride(res) if res is not None else 0, M, N, a.Kp, float(w.scale_inv),
                                    flags, _stream()), "cra5_gemm_nt_split")
     if ev is not None:
@@ -296,9 +330,11 @@ def gemm_unembed(a, w, C, H, W, kh, kw, sh, sw, side, mean=None, std=None, out=N
         out = torch.empty((C, H, W), device=a.data.device, dtype=torch.float32)
     assert out.is_contiguous() and tuple(out.shape) == (C, H, W) and side.is_contiguous()
     ev = TIMER.start() if TIMER is not None else None
-    check(lib().cra5_gemm_nt_split_unembed(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out), _p(side),
+    hi = (1 if hi_only else 0) | (2 if a.plain else 0) | (4 if w.plain else 0)
+    assert hi in (0, 1) or hi_only, "plain-f16 operands exist in the reduced-precision mode only"
+    check(lib().cra5_gemm_nt_split_unembed(_p(a.data), a.pitch, _p(w.data), w.pitch, _p(out), _p(side),
                                            side.numel() * side.element_size(), _p(mean), _p(std), a.rows, a.Kp,
-                                           float(w.scale_inv), C, H, W, kh, kw, sh, sw, int(bool(hi_only)), _stream()),
+                                           float(w.scale_inv), C, H, W, kh, kw, sh, sw, hi, _stream()),
           "cra5_gemm_nt_split_unembed")
     if ev is not None:
         TIMER.stop("gemm_nt_split", ev, 2.0 * a.rows * w.rows * a.K)
@@ -325,6 +361,8 @@ def small_gemm_nt_split(a, w, bias=None, res=None, gelu=False, out=None, out_spl
         assert out_split.rows == M and out_split.K == N
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_GELU if gelu else 0) | (EPI_RES if res is not None else 0)
     ev = TIMER.start() if TIMER is not None else None
+    if out_split is not None:
+        out_split.plain = False      # (split rows: workspace matrices change layout with the mode)
     check(lib().cra5_small_gemm_nt_split(_p(a.data), a.Kp, _p(w.data), w.Kp, _p(out),
                                          _row_stride(out) if (out is not None and unembed is None) else 0,
                                          _p(out_split.data) if out_split is not None else None,
@@ -347,6 +385,8 @@ def hyper_attention(qkv, heads, out=None, out_split=None, want_f32=True):
     if out_split is not None:
         assert out_split.rows == n and out_split.K == C
     ev = TIMER.start() if TIMER is not None else None
+    if out_split is not None:
+        out_split.plain = False      # (split rows: workspace matrices change layout with the mode)
     check(lib().cra5_hyper_attention_f32(_p(qkv), _p(out), _p(out_split.data) if out_split is not None else None,
                                          out_split.Kp if out_split is not None else 0, n, C, heads,
                                          float((C // heads) ** -0.5), _stream()), "cra5_hyper_attention_f32")
@@ -355,7 +395,7 @@ def hyper_attention(qkv, heads, out=None, out_split=None, want_f32=True):
     return out if out is not None else out_split
 
 
-def layernorm(x, gamma, beta, eps=1e-6, out=None, out_split=None, want_f32=True):
+def layernorm(x, gamma, beta, eps=1e-6, out=None, out_split=None, want_f32=True, out_plain=False):
     _dev(x, gamma, beta, out)
     rows, D = x.shape
     if out is None and want_f32:
@@ -366,8 +406,11 @@ def layernorm(x, gamma, beta, eps=1e-6, out=None, out_split=None, want_f32=True)
     check(lib().cra5_layernorm_f32(_p(x), _row_stride(x), _p(gamma), _p(beta), _p(out),
                                    _row_stride(out) if out is not None else 0,
                                    _p(out_split.data) if out_split is not None else None,
-                                   out_split.Kp if out_split is not None else 0, rows, D, float(eps), _stream()),
+                                   out_split.Kp if out_split is not None else 0, rows, D, float(eps),
+                                   int(bool(out_plain)), _stream()),
           "cra5_layernorm_f32")
+    if out_split is not None:
+        out_split.plain = bool(out_plain)
     if ev is not None:   # bytes: the row read once + every output written once
         # (the 648-row hyper-prior LayerNorms are launch-latency-bound: kept out of the HBM-bound figure)
         TIMER.stop("layernorm" if rows >= 4096 else "layernorm_small", ev,
@@ -389,6 +432,8 @@ def window_attention(qkv, pad_row, heads, H, W, wh, ww, out=None, out_split=None
         assert out_split.rows == N and out_split.K == C
     scale = float((C // heads) ** -0.5)
     ev = TIMER.start() if TIMER is not None else None
+    if out_split is not None:
+        out_split.plain = False      # (split rows: workspace matrices change layout with the mode)
     check(lib().cra5_window_attention_f32(_p(qkv), _p(pad_row), _p(out),
                                           _p(out_split.data) if out_split is not None else None,
                                           out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
@@ -424,13 +469,23 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
     if out_split is not None:
         assert out_split.rows == N and out_split.K == C
     scale = float((C // heads) ** -0.5)
+    # reduced-precision mode on PLAIN rows (hi_only = 3 in the C ABI): the qkv GEMM wrote them plain; the pad row must be
+    # plain too and out_split is written plain
+    hi_flag = int(bool(hi_only))
+    if qkv_s.plain:
+        assert hi_only and pad_s.plain, "plain qkv rows need the reduced-precision mode and a plain pad row"
+        hi_flag = 3
+    else:
+        assert not pad_s.plain
+    if out_split is not None:
+        out_split.plain = hi_flag == 3
     ev = TIMER.start() if TIMER is not None else None
     if workspace is not None or balanced:
         assert workspace is None or (workspace.is_cuda and workspace.is_contiguous())
         check(lib().cra5_window_attention_split_ws(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
                                                    _p(out_split.data) if out_split is not None else None,
                                                    out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
-                                                   scale, int(bool(hi_only)),
+                                                   scale, hi_flag,
                                                    ctypes.c_void_p(workspace.data_ptr()) if workspace is not None else None,
                                                    workspace.numel() * workspace.element_size() if workspace is not None else 0,
                                                    _stream()),
@@ -439,7 +494,7 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
         check(lib().cra5_window_attention_split(_p(qkv_s.data), qkv_s.Kp, _p(pad_s.data), _p(out),
                                                 _p(out_split.data) if out_split is not None else None,
                                                 out_split.Kp if out_split is not None else 0, C, heads, H, W, wh, ww,
-                                                scale, int(bool(hi_only)), _stream()), "cra5_window_attention_split")
+                                                scale, hi_flag, _stream()), "cra5_window_attention_split")
     if ev is not None:
         TIMER.stop("window_attention_split", ev, 4.0 * N * (wh * ww) * C)
     return out if out is not None else out_split
@@ -468,6 +523,7 @@ def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split
     if out_split is not None:
         assert out_split.rows == Hp * Wp and out_split.K == K
         ev = TIMER.start() if TIMER is not None else None
+        out_split.plain = False
         check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), None, _p(out_split.data), C, H, W, kh, kw, sh, sw, Hp,
                                     Wp, out_split.Kp, _stream()), "cra5_im2col_f32")
         if ev is not None:   # bytes: the frame read once + the patch matrix written once

@@ -316,6 +316,12 @@ class VAEformer(nn.Module):
         self.precision = os.environ.get("CRA5_PRECISION", "fp32")
         if self.precision not in ("fp32", "f16"):
             raise ValueError("CRA5_PRECISION must be 'fp32' or 'f16'")
+        # reduced-precision mode: "plain" (default, round 5) - activations and weights of g_a / g_s travel as PLAIN f16
+        # rows wherever the consuming kernel takes them (full 128-byte lines per k-step: -13..-18 % per GEMM launch,
+        # bit-identical results); "split" keeps the hi planes of split rows (rounds 1-4; A / B runs, tests)
+        self.f16_layout = os.environ.get("CRA5_F16_LAYOUT", "plain")
+        if self.f16_layout not in ("plain", "split"):
+            raise ValueError("CRA5_F16_LAYOUT must be 'plain' or 'split'")
         self._derived = {}
         self._derive_lock = threading.RLock()
         self._gpu_lock = threading.Lock()
@@ -538,6 +544,15 @@ class VAEformer(nn.Module):
         """Split-f16 copy of a weight, scaled by a per-tensor power of two (cached)."""
         return self._derive("ws." + key, w, lambda w: ops.split_f16(self._weight2d(key, w).contiguous(), "auto"))
 
+    def _wplain(self, key, w):
+        """PLAIN f16 copy of a weight (the hi plane of its split copy, same power-of-two scale), cached."""
+        return self._derive("wpl." + key, w, lambda _w: self._wsplit(key, w).plain_copy())
+
+    def _plain_gemm(self, key, M, N, K):
+        """Does the reduced-precision GEMM `key` of shape M x N x K run on plain-f16 operands?"""
+        return (self.precision == "f16" and self.f16_layout == "plain" and self.gemm_mode == "split"
+                and key.startswith(("g_a.", "g_s.")) and ops.plain_ok(M, N, _rup(K, 32)))
+
     def _wf32(self, key, w, pad32=False):
         w2 = self._weight2d(key, w)
         if pad32 and w2.shape[1] % 32:
@@ -554,24 +569,30 @@ class VAEformer(nn.Module):
             return ops.split_f16(t, out=self._sbuf(name, t.shape[0], t.shape[1]))
         return t
 
-    def _ln(self, x, norm, name):
+    def _ln(self, x, norm, name, plain=False):
         rows, D = x.shape
         if self.gemm_mode == "split":
             sm = self._sbuf(name, rows, D)
-            ops.layernorm(x, norm.weight, norm.bias, 1e-6, out_split=sm, want_f32=False)
+            ops.layernorm(x, norm.weight, norm.bias, 1e-6, out_split=sm, want_f32=False, out_plain=plain)
             return sm
         return ops.layernorm(x, norm.weight, norm.bias, 1e-6, out=self._buf(name, (rows, D)))
 
-    def _mm(self, a, key, w, bias=None, res=None, gelu=False, out=None, out_name=None):
+    def _mm(self, a, key, w, bias=None, res=None, gelu=False, out=None, out_name=None, out_plain=False):
         """epi(a @ W^T).  `out`: fp32 destination (tensor / strided view) or None; `out_name`:
         produce the result as the next GEMM's input (split engine: written split by the
-        epilogue, no fp32 copy; f32 engine: a named fp32 workspace)."""
+        epilogue, no fp32 copy; f32 engine: a named fp32 workspace).  out_plain: reduced-precision mode, the named
+        result's rows are plain f16 (the caller has checked that its consumer takes them)."""
         if self.gemm_mode == "split":
             W = self._wsplit(key, w)
             hi = self.precision == "f16" and key.startswith(("g_a.", "g_s."))
+            if self._plain_gemm(key, a.rows, W.rows, W.K):
+                W = self._wplain(key, w)
+            else:
+                assert not a.plain and not out_plain, key
             if out_name is not None:
                 sm = self._sbuf(out_name, a.rows, W.rows)
-                ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False, hi_only=hi)
+                ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out_split=sm, want_f32=False, hi_only=hi,
+                                  out_plain=out_plain)
                 return sm
             return ops.gemm_nt_split(a, W, bias=bias, res=res, gelu=gelu, out=out, hi_only=hi)
         W = self._wf32(key, w, pad32=(a.shape[1] % 32 == 0 and self._weight2d(key, w).shape[1] != a.shape[1]))
@@ -586,12 +607,21 @@ class VAEformer(nn.Module):
         N, D = t_in.shape
         H, W = grid
         split = self.gemm_mode == "split"
-        h = self._ln(t_in, blk.norm1, f"h{D}")
         wh, ww = blk.window if blk.window is not None else (H, W)
-        if split and self.attn_mode == "split" and ops.split_attention_ok(D, blk.heads, wh, ww, H, W):
+        fused_attn = split and self.attn_mode == "split" and ops.split_attention_ok(D, blk.heads, wh, ww, H, W)
+        # reduced-precision mode: which matrices of the block travel as plain f16 rows - a producer writes plain only
+        # when its consumer's GEMM takes plain operands (and, for an epilogue, when its own launch is the wide form)
+        p_qkv, p_proj = (self._plain_gemm(pre + ".attn.qkv", N, 3 * D, D), self._plain_gemm(pre + ".attn.proj", N, D, D))
+        p_fc1, p_fc2 = (self._plain_gemm(pre + ".mlp.fc1", N, 4 * D, D), self._plain_gemm(pre + ".mlp.fc2", N, D, 4 * D))
+        h = self._ln(t_in, blk.norm1, f"h{D}", plain=p_qkv)
+        if fused_attn:
             # qkv never exists in fp32: GEMM epilogue -> split-f16 -> f16-MFMA attention -> split
-            qkv_s = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out_name=f"qkv{D}")
-            pad_s = self._derive("pad." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)))
+            qkv_s = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias, out_name=f"qkv{D}",
+                             out_plain=p_qkv and p_proj)
+            if qkv_s.plain:
+                pad_s = self._derive("padp." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)).plain_copy())
+            else:
+                pad_s = self._derive("pad." + pre, blk.attn.qkv.bias, lambda b: ops.split_f16(b.reshape(1, -1)))
             att = self._sbuf(f"att{D}", N, D, zero=True)
             ws, bal = None, False
             if blk.window is None and self.attn_balanced:
@@ -602,9 +632,9 @@ class VAEformer(nn.Module):
             ops.window_attention_split(qkv_s, pad_s, blk.heads, H, W, wh, ww, out_split=att, workspace=ws, balanced=bal,
                                        hi_only=self.precision == "f16" and pre.startswith(("g_a.", "g_s.")))
             self._mm(att, pre + ".attn.proj", blk.attn.proj.weight, bias=blk.attn.proj.bias, res=t_in, out=t_out)
-            h = self._ln(t_out, blk.norm2, f"h{D}")
+            h = self._ln(t_out, blk.norm2, f"h{D}", plain=p_fc1)
             hid = self._mm(h, pre + ".mlp.fc1", blk.mlp.fc1.weight, bias=blk.mlp.fc1.bias, gelu=True,
-                           out_name=f"hid{D}")
+                           out_name=f"hid{D}", out_plain=p_fc1 and p_fc2)
             self._mm(hid, pre + ".mlp.fc2", blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias, res=t_out, out=t_out)
             return t_out
         qkv = self._mm(h, pre + ".attn.qkv", blk.attn.qkv.weight, bias=blk.attn.qkv.bias,
@@ -758,15 +788,19 @@ class VAEformer(nn.Module):
                  bias=self.post_quant_conv.bias, out=t)
         for j, blk in enumerate(self.g_s.blocks):
             self._block(blk, f"g_s.blocks.{j}", t, t, (self.Hp, self.Wp))
-        h = self._ln(t, self.g_s.norm, f"h{D}")
         Cout, (Himg, Wimg) = cfg['out_chans'], cfg['img_size']
+        # reduced-precision mode: the fused un-embed (always the 256 x 256 wide form) takes plain operands when D % 64 == 0
+        p_ue = (self.precision == "f16" and self.f16_layout == "plain" and self.gemm_mode == "split" and D % 64 == 0
+                and self.fused_unembed and D <= 8192 and ops.unembed_side_bytes(Cout, Himg, Wimg, kh, kw, sh, sw) > 0)
+        h = self._ln(t, self.g_s.norm, f"h{D}", plain=p_ue)
         x_hat = torch.empty((Cout, Himg, Wimg), device=self.device, dtype=torch.float32)
         nside = ops.unembed_side_bytes(Cout, Himg, Wimg, kh, kw, sh, sw) if self.gemm_mode == "split" else 0
         if nside and self.fused_unembed and D <= 8192:
             # ONE fused launch pair: the GEMM epilogue scatters into the reconstruction (de-normalised), the overlap
             # rows go through a 2-rows-per-patch-row side buffer (no [tokens][C*110] column matrix, no overlap-add pass)
             side = self._buf("ue_side", (nside // 4,))
-            ops.gemm_unembed(h, self._wsplit("g_s.final", self.g_s.final.weight), Cout, Himg, Wimg, kh, kw, sh, sw, side,
+            wue = self._wplain("g_s.final", self.g_s.final.weight) if p_ue else self._wsplit("g_s.final", self.g_s.final.weight)
+            ops.gemm_unembed(h, wue, Cout, Himg, Wimg, kh, kw, sh, sw, side,
                              mean=mean, std=std, out=x_hat, hi_only=self.precision == "f16")
             return x_hat
         ncol = Cout * kh * kw

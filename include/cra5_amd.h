@@ -134,6 +134,13 @@ int cra5_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *
  * A / W is read, and only the hi plane of C_split is WRITTEN (its lo halves keep whatever they held: a
  * consumer of that matrix must run in this mode too). */
 #define CRA5_GEMM_HI_ONLY 8
+/* With CRA5_GEMM_HI_ONLY (big tiles, Kp % 64 == 0; CRA5_ERR_ARG otherwise): the operand / the split output is a PLAIN f16
+ * matrix - a row is its k-values as contiguous halves (`lda_kp` / `ldw_kp` / `ldc_split_kp` then count HALVES per row:
+ * a plain row may live in the first half of a split-layout row, pitch 2 * Kp).  One full 128-byte line per row and
+ * 64-wide k-step instead of two half-lines: -13..-18 % per launch, bit-identical results. */
+#define CRA5_GEMM_A_PLAIN 16
+#define CRA5_GEMM_W_PLAIN 32
+#define CRA5_GEMM_OUT_PLAIN 64
 int cra5_gemm_nt_f32(const float *A, int lda, const float *W, int ldw, float *C, int ldc,
                      const float *bias, const float *res, int ldr, int M, int N, int K,
                      int flags, void *stream);
@@ -161,10 +168,12 @@ int cra5_split_f16(const float *x, int ldx, uint16_t *out, int rows, int K, int 
 /* LayerNorm over the last dim (eps inside the sqrt), one row per wavefront
  * (partial(nn.LayerNorm, eps=1e-6): vit_nlc.py:266,278,381,626). D % 4 == 0, D <= 2048.
  * Outputs: y (fp32, may be NULL) and/or y_split (split-f16 rows of 2*split_kp halves, pad
- * columns zeroed, may be NULL). */
+ * columns zeroed, may be NULL).  split_plain != 0 (reduced-precision mode): y_split rows are PLAIN f16 - D
+ * contiguous halves (+ zero pad to split_kp) at the start of each 2*split_kp-halves row - for a consumer
+ * running with CRA5_GEMM_A_PLAIN. */
 int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float *beta, float *y,
                        int ldy, uint16_t *y_split, int split_kp, int rows, int D, float eps,
-                       void *stream);
+                       int split_plain, void *stream);
 
 /* ============================ device: attention =============================== */
 

@@ -32,7 +32,7 @@ def test_argument_validation_without_gpu():
     CRA5_ERR_ARG (-7) even on a box with no GPU."""
     L = _lib.lib()
     assert L.cra5_gemm_nt_f32(None, 0, None, 0, None, 0, None, None, 0, 1, 1, 4, 0, None) == -7
-    assert L.cra5_layernorm_f32(None, 0, None, None, None, 0, None, 0, 1, 3, 1e-6, None) == -7
+    assert L.cra5_layernorm_f32(None, 0, None, None, None, 0, None, 0, 1, 3, 1e-6, 0, None) == -7
     assert L.cra5_window_attention_f32(None, None, None, None, 0, 64, 1, 1, 1, 1, 1, 1.0, None) == -7
     assert L.cra5_gemm_nt_split(None, 32, None, 32, None, 0, None, 0, None, None, 0, 1, 1, 32, 1.0, 0, None) == -7
     assert L.cra5_split_f16(None, 0, None, 1, 1, 32, 1.0, None) == -7

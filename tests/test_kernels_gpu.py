@@ -499,6 +499,95 @@ def test_gemm_hi_only_is_plain_f16(dev, M, N, K):
     assert 1e-5 < e < 5e-3, e
 
 
+def _hi_plane(sm):
+    """the hi halves of a split matrix as a [rows, Kp] int16 tensor"""
+    return sm.data.view(sm.rows, sm.Kp // 32, 2, 32)[:, :, 0].reshape(sm.rows, sm.Kp)
+
+
+def _plain_rows_of(sm_split_layout_buffer):
+    """a plain matrix living in the first half of every row of a split-layout buffer (what the model's workspaces hold)"""
+    sm = ops.SplitMat.empty(sm_split_layout_buffer.rows, sm_split_layout_buffer.K, sm_split_layout_buffer.data.device, zero=True)
+    sm.data[:, : sm.Kp] = _hi_plane(sm_split_layout_buffer)
+    sm.plain = True
+    return sm
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(2048, 4096, 1024, "gelu_out"), (10368, 1024, 1024, "res"), (10368, 3072, 1024, "bias_out"),
+                                       (2048, 2048, 8192 + 64 * 5, "res"), (4096, 1024, 29480, "bias")])
+def test_gemm_plain_f16_operands_equal_the_split_hi_planes(dev, M, N, K, epi):
+    """Round 5, reduced-precision mode: CRA5_GEMM_A_PLAIN / _W_PLAIN / _OUT_PLAIN (a row = contiguous halves: one full
+    128-byte line per 64-wide k-step) against the same launch on split rows' hi planes - the SAME arithmetic in the same
+    order: fp32 outputs bit-identical, the plain output row == the hi plane of the split output.  Every combination of
+    plain / split A and W; long K chained in 64-multiples."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    r = torch.randn(M, N, generator=g).to(dev) if epi == "res" else None
+    sa, sw = ops.split_f16(a), ops.split_f16(w, "auto")
+    pa, pw = _plain_rows_of(sa), sw.plain_copy()
+    assert torch.equal(pw.data, _hi_plane(sw)) and pw.plain and pw.pitch == sw.Kp and pa.pitch == 2 * sa.Kp
+    kw = dict(bias=b, res=r, gelu="gelu" in epi, hi_only=True)
+    if epi.endswith("_out"):
+        ref = ops.SplitMat.empty(M, N, dev, zero=True)
+        ops.gemm_nt_split(sa, sw, out_split=ref, want_f32=False, **kw)
+        for A_, W_ in ((pa, pw), (sa, pw), (pa, sw)):
+            got = ops.SplitMat.empty(M, N, dev, zero=True)
+            ops.gemm_nt_split(A_, W_, out_split=got, want_f32=False, out_plain=True, **kw)
+            assert got.plain and torch.equal(got.data[:, : got.Kp], _hi_plane(ref))
+            assert torch.count_nonzero(got.data[:, got.Kp:]) == 0          # nothing written past the plain row
+            assert torch.equal(got.to_float(), ref.data.view(torch.float16).view(M, -1, 2, 32)[:, :, 0].reshape(M, -1)[:, :N].float())
+    else:
+        ref = ops.gemm_nt_split(sa, sw, **kw)
+        for A_, W_ in ((pa, pw), (sa, pw), (pa, sw)):
+            assert torch.equal(ops.gemm_nt_split(A_, W_, **kw), ref)
+    # the flags are refused where the wide form does not run (fp32-accurate mode, small launches)
+    with pytest.raises(Exception):
+        ops.gemm_nt_split(pa, pw, bias=b)
+    with pytest.raises(Exception):
+        ops.gemm_nt_split(_plain_rows_of(ops.split_f16(a[:256])), pw, hi_only=True)
+
+
+def test_layernorm_plain_rows(dev):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(1000, 1024, generator=g) * 3 + 0.5).to(dev)
+    gam, bet = (1 + 0.1 * torch.randn(1024, generator=g)).to(dev), (0.1 * torch.randn(1024, generator=g)).to(dev)
+    s_split, s_plain = ops.SplitMat.empty(1000, 1024, dev, zero=True), ops.SplitMat.empty(1000, 1024, dev, zero=True)
+    ops.layernorm(x, gam, bet, 1e-6, out_split=s_split, want_f32=False)
+    ops.layernorm(x, gam, bet, 1e-6, out_split=s_plain, want_f32=False, out_plain=True)
+    assert s_plain.plain and not s_split.plain
+    assert torch.equal(s_plain.data[:, :1024], _hi_plane(s_split)) and torch.count_nonzero(s_plain.data[:, 1024:]) == 0
+
+
+@pytest.mark.parametrize("ws", [(24, 24), (48, 12), None])
+def test_window_attention_plain_rows_equal_the_hi_only_split_launch(dev, ws):
+    """hi_only = 3 in the C ABI: plain qkv / pad rows in, plain rows out - bit-identical to the reduced-precision launch on
+    split rows (same f16 values, same order), for windows (incl. the padded shape), the plain whole-grid launch and the
+    balanced one with its merge kernel."""
+    H, W, C, heads = 72, 144, 128, 2
+    g = torch.Generator().manual_seed(12)
+    qkv = torch.randn(H * W, 3 * C, generator=g).to(dev)
+    bias = torch.randn(1, 3 * C, generator=g).to(dev)
+    qs, ps = ops.split_f16(qkv), ops.split_f16(bias)
+    qp, pp = _plain_rows_of(qs), ps.plain_copy()
+    wh, ww = ws if ws is not None else (H, W)
+    for balanced in ((False, True) if ws is None else (False,)):
+        wsb = None
+        if balanced:
+            ok, nb = ops.attention_balanced_plan(H * W, heads)
+            if not ok:
+                continue
+            wsb = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+        o_s, o_p = ops.SplitMat.empty(H * W, C, dev, zero=True), ops.SplitMat.empty(H * W, C, dev, zero=True)
+        f_s = torch.empty(H * W, C, device=dev)
+        f_p = torch.empty(H * W, C, device=dev)
+        ops.window_attention_split(qs, ps, heads, H, W, wh, ww, out=f_s, out_split=o_s, hi_only=True, workspace=wsb, balanced=balanced or None)
+        ops.window_attention_split(qp, pp, heads, H, W, wh, ww, out=f_p, out_split=o_p, hi_only=True, workspace=wsb, balanced=balanced or None)
+        assert o_p.plain and not o_s.plain
+        assert torch.equal(f_p, f_s)
+        assert torch.equal(o_p.data[:, :C], _hi_plane(o_s)) and torch.count_nonzero(o_p.data[:, C:]) == 0
+
+
 def test_split_attention_shape_rule(dev):
     """Windows that are not the whole grid keep a per-block row-offset table: more than
     ops.MAX_WIN_TOKENS tokens per window is refused by the C ABI (the model then uses the exact-f32

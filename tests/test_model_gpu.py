@@ -757,6 +757,31 @@ def test_full268_reduced_precision_mode(big, dev, golden_dir):
     assert rmse(sub(y2, 499), g["y_sub"]) <= 1e-5
 
 
+def test_reduced_precision_plain_layout_equals_the_split_layout(big, thin, dev):
+    """Round 5: in the reduced-precision mode activations / weights of g_a and g_s travel as PLAIN f16 rows wherever the
+    consuming kernel takes them (CRA5_F16_LAYOUT=plain, the default) - a different memory layout of the same f16 values:
+    y, x_hat and the streams equal those of the split layout (rounds 1-4) BIT FOR BIT, on the 268 model (every GEMM of
+    a block plain) and on the thin one (only its fc1 / fc2 are wide enough: the mixed case)."""
+    for net, C, L in ((big, 268, 256), (thin, 8, 16)):
+        x = synth.synth_frame(C, seed=6).unsqueeze(0).to(dev)
+        keep = (net.precision, net.f16_layout)
+        res = {}
+        try:
+            net.precision = "f16"
+            for lay in ("split", "plain"):
+                net.f16_layout = lay
+                y = net.encode_latent(x, type='float')[0]
+                x_hat = net.decode_latent(synth_yhat(L, 5).to(dev))
+                out = net.compress(x)
+                res[lay] = (y.clone(), x_hat.clone(), out["strings"])
+        finally:
+            net.precision, net.f16_layout = keep
+        assert torch.equal(res["plain"][0], res["split"][0]), C
+        assert torch.equal(res["plain"][1], res["split"][1]), C
+        assert res["plain"][2] == res["split"][2], C
+        assert bool(torch.isfinite(res["plain"][1]).all())
+
+
 def test_thin_batch_of_two_frames(thin, dev):
     """B > 1 through the public API: strings come back per frame (vaeformer.py:399-401 layout
     [y_strings, z_strings], each a list of B byte strings) and every frame equals its B=1 result."""
