@@ -907,8 +907,8 @@ def main():
             xh16 = net.decode_latent(y_hat)
             e_y, e_x, y_rms = rm(y16, y32), rm(xh16, xh32), float(torch.sqrt(torch.mean(y32.double() ** 2)))
             del y32, y16, xh32, xh16, y_hat
-            n16 = 2 * args.inflight
-            pipe.map(round_trip, [frames[i % pool] for i in range(args.inflight)])       # first use of the f16 instantiations
+            n16 = 4 * args.inflight
+            pipe.map(round_trip, [frames[i % pool] for i in range(2 * args.inflight)])   # first use of the f16 instantiations
             torch.cuda.synchronize()
             t16 = time.perf_counter()
             r16 = pipe.map(round_trip, [frames[i % pool] for i in range(n16)])
@@ -922,7 +922,9 @@ def main():
                         "test_full268_reduced_precision_mode asserts it against the reference golden)",
                 "what": "same pipeline and frames as the timed region with CRA5_PRECISION=f16 (1 MFMA per product in g_a / "
                         "g_s GEMMs and attention; h_a / h_s / entropy side unchanged so both sides derive the same CDF "
-                        f"indexes); {n16}-frame region after one warm batch, outside the timed region"}
+                        f"indexes); g_a / g_s activations and weights as PLAIN f16 rows (CRA5_F16_LAYOUT={net.f16_layout}); "
+                        f"{n16}-frame region after two warm batches, outside the timed region",
+                "frac_of_f16_roofline": FLOP_PER_FRAME * n16 / t16 / (PEAK_F16_MFMA_TFLOPS * 1e12)}
         except Exception as ex:  # noqa: BLE001
             result["precision_f16"] = {"value": None, "error": repr(ex)}
         finally:

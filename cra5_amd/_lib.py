@@ -62,7 +62,7 @@ SIGNATURES = {
     "cra5_attention_balanced_plan": (c_int, [c_int, c_int, P(c_size_t)]),
     "cra5_window_attention_split_ws": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                                c_int, c_int, c_int, c_float, c_int, c_void_p, c_size_t, c_void_p]),
-    "cra5_im2col_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "cra5_im2col_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "cra5_col2im_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "cra5_probe_sums_f32": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "cra5_transpose_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                      const float *__restrict__ stdv, float *__restrict__ cols,
                                                      unsigned short *__restrict__ cols_s, int C, int H, int W,
-                                                     int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk) {
+                                                     int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk, int plain) {
   const int K = C * kh * kw;
   const size_t total = (size_t)Hp * Wp * K;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
     float v = x[((size_t)c * H + (ph * sh + i)) * W + (pw * sw + j)];
     if (mean) v = (v - mean[c]) / stdv[c];
     if (cols) cols[(size_t)tok * ldk + k] = v;
-    if (cols_s) cra5_store_split(cols_s + (size_t)tok * 2 * ldk, k, v);
+    if (cols_s) {
+      if (plain) cra5_store_plain(cols_s + (size_t)tok * 2 * ldk, k, v);
+      else cra5_store_split(cols_s + (size_t)tok * 2 * ldk, k, v);
+    }
   }
 }
 
@@ -171,7 +174,7 @@ template <int KH, int KW>
 __global__ __launch_bounds__(256) void im2col_tiled_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                            const float *__restrict__ stdv, float *__restrict__ cols,
                                                            unsigned short *__restrict__ cols_s, int C, int H, int W,
-                                                           int sh, int Hp, int Wp, int ldk) {
+                                                           int sh, int Hp, int Wp, int ldk, int plain) {
   constexpr int SEG = TILE_TOK * KW;             // floats per staged image-row segment
   constexpr int TS = TILE_CH * KH * KW + 4;      // LDS token stride (floats)
   static_assert((TILE_CH * KH * KW) % 4 == 0, "a block's K offset must stay 16-byte aligned");
@@ -230,13 +233,28 @@ __global__ __launch_bounds__(256) void im2col_tiled_kernel(const float *__restri
     const size_t tok = (size_t)ph * Wp + pwt * TILE_TOK + t;
     if (k4 + 4 <= kpt) {
       if (cols) *reinterpret_cast<float4 *>(cols + tok * ldk + kbase + k4) = v;
-      if (cols_s) cra5_store_split4(cols_s + tok * 2 * ldk, kbase + k4, v.x, v.y, v.z, v.w);
+      if (cols_s) {   // (plain: the reduced-precision mode's rows - element k at half k of the 2 * ldk-halves row)
+        if (plain) cra5_store_plain4(cols_s + tok * 2 * ldk, kbase + k4, v.x, v.y, v.z, v.w);
+        else cra5_store_split4(cols_s + tok * 2 * ldk, kbase + k4, v.x, v.y, v.z, v.w);
+      }
     } else {   // ragged end of the last channel chunk (e.g. 159 = 19*8 + 7 channels)
       const float vv[4] = {v.x, v.y, v.z, v.w};
       for (int u = 0; k4 + u < kpt; ++u) {
         if (cols) cols[tok * ldk + kbase + k4 + u] = vv[u];
-        if (cols_s) cra5_store_split(cols_s + tok * 2 * ldk, kbase + k4 + u, vv[u]);
+        if (cols_s) {
+          if (plain) cra5_store_plain(cols_s + tok * 2 * ldk, kbase + k4 + u, vv[u]);
+          else cra5_store_split(cols_s + tok * 2 * ldk, kbase + k4 + u, vv[u]);
+        }
       }
+    }
+  }
+  // plain rows: the K padding (C*KH*KW .. ldk) is written every time - the same workspace holds split rows in the
+  // fp32-accurate mode, whose lo planes lie where a plain row has its padding
+  if (plain && cols_s && cc == n_cc - 1) {
+    const int K = C * KH * KW, npad = ldk - K;
+    for (int e = threadIdx.x; e < TILE_TOK * npad; e += 256) {
+      const int t = e / npad, k = K + (e - t * npad);
+      cols_s[((size_t)ph * Wp + pwt * TILE_TOK + t) * 2 * ldk + k] = 0;
     }
   }
 }
@@ -712,7 +730,7 @@ int cra5_layernorm_f32(const float *x, int ldx, const float *gamma, const float 
 }
 
 int cra5_im2col_f32(const float *x, const float *mean, const float *stdv, float *cols, uint16_t *cols_split, int C,
-                    int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk, void *stream) {
+                    int H, int W, int kh, int kw, int sh, int sw, int Hp, int Wp, int ldk, int split_plain, void *stream) {
   if (!x || (!cols && !cols_split) || C <= 0 || ldk < C * kh * kw) return CRA5_ERR_ARG;
   if (cols_split && (ldk % 32)) return CRA5_ERR_ARG;
   if ((Hp - 1) * sh + kh > H || (Wp - 1) * sw + kw > W) return CRA5_ERR_ARG;
@@ -722,12 +740,13 @@ int cra5_im2col_f32(const float *x, const float *mean, const float *stdv, float 
       ((uintptr_t)x & 15) == 0) {
     const int blocks = (Wp / TILE_TOK) * Hp * ((C + TILE_CH - 1) / TILE_CH);
     hipLaunchKernelGGL((im2col_tiled_kernel<11, 10>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, mean, stdv,
-                       cols, cols_split, C, H, W, sh, Hp, Wp, ldk);
+                       cols, cols_split, C, H, W, sh, Hp, Wp, ldk, split_plain);
     return (int)hipGetLastError();
   }
+  if (split_plain && ldk != C * kh * kw) return CRA5_ERR_ARG;   // (the generic kernel does not re-zero a plain row's padding)
   const size_t total = (size_t)Hp * Wp * C * kh * kw;
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, cols,
-                     cols_split, C, H, W, kh, kw, sh, sw, Hp, Wp, ldk);
+                     cols_split, C, H, W, kh, kw, sh, sw, Hp, Wp, ldk, split_plain);
   return (int)hipGetLastError();
 }
 

@@ -511,7 +511,7 @@ def split_attention_ok(C, heads, wh, ww, H=None, W=None):
             and (L <= MAX_WIN_TOKENS or (wh == H and ww == W)))
 
 
-def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split=None):
+def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split=None, out_plain=False):
     """x: [C,H,W] -> cols [Hp*Wp, ldk] (column (c*kh+i)*kw+j); pad columns are zero.  With
     out_split (a ZERO-initialised SplitMat [Hp*Wp, C*kh*kw]) the split-f16 form is written
     instead of the fp32 one."""
@@ -523,9 +523,9 @@ def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split
     if out_split is not None:
         assert out_split.rows == Hp * Wp and out_split.K == K
         ev = TIMER.start() if TIMER is not None else None
-        out_split.plain = False
+        out_split.plain = bool(out_plain)
         check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), None, _p(out_split.data), C, H, W, kh, kw, sh, sw, Hp,
-                                    Wp, out_split.Kp, _stream()), "cra5_im2col_f32")
+                                    Wp, out_split.Kp, int(bool(out_plain)), _stream()), "cra5_im2col_f32")
         if ev is not None:   # bytes: the frame read once + the patch matrix written once
             TIMER.stop("im2col", ev, 4.0 * C * H * W + 4.0 * Hp * Wp * K)
         return out_split
@@ -534,7 +534,7 @@ def im2col(x, kh, kw, sh, sw, ldk=None, mean=None, std=None, out=None, out_split
         out = torch.zeros((Hp * Wp, ldk), device=x.device, dtype=torch.float32)
     assert out.is_contiguous() and out.shape[1] == ldk
     check(lib().cra5_im2col_f32(_p(x), _p(mean), _p(std), _p(out), None, C, H, W, kh, kw, sh, sw, Hp, Wp, ldk,
-                                _stream()), "cra5_im2col_f32")
+                                0, _stream()), "cra5_im2col_f32")
     return out
 
 

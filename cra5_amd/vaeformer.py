@@ -663,7 +663,11 @@ class VAEformer(nn.Module):
         x = x.contiguous()
         if self.gemm_mode == "split":
             cols = self._sbuf("pe_cols", N, K, zero=True)   # K padding written once, never touched
-            ops.im2col(x, kh, kw, sh, sw, mean=mean, std=std, out_split=cols)
+            # (reduced-precision mode: plain rows - half the bytes written, full lines for the patch-embed GEMM; the ERA5
+            # geometry's tiled gather re-zeroes a plain row's padding itself)
+            p_pe = (kh, kw, sh, sw) == (11, 10, 10, 10) and self.Wp % 16 == 0 and \
+                self._plain_gemm("g_a.patch_embed.proj", N, D, K)
+            ops.im2col(x, kh, kw, sh, sw, mean=mean, std=std, out_split=cols, out_plain=p_pe)
         else:
             cols = self._buf("pe_cols", (N, _rup(K, 32)), zero=True)
             ops.im2col(x, kh, kw, sh, sw, ldk=cols.shape[1], mean=mean, std=std, out=cols)

@@ -242,10 +242,11 @@ int cra5_gemm_nt_split_unembed(const uint16_t *A, int lda_kp, const uint16_t *W_
  * normalisation (x - mean[c]) / std[c] (cra5_api.py:264-266) when mean != NULL.
  * x: [C][H][W]; cols: [Hp*Wp][ldk], column (c*kh + i)*kw + j; columns >= C*kh*kw are
  * left untouched (keep them zero).  cols (fp32) and/or cols_split (split-f16, Kp = ldk,
- * ldk % 32 == 0) may be NULL. */
+ * ldk % 32 == 0) may be NULL.  split_plain != 0 (reduced-precision mode): cols_split rows are PLAIN f16 - C*kh*kw
+ * contiguous halves, zero padded to ldk, at the start of each 2*ldk-halves row (ERA5 patch geometry, or ldk == C*kh*kw). */
 int cra5_im2col_f32(const float *x, const float *mean, const float *std, float *cols,
                     uint16_t *cols_split, int C, int H, int W, int kh, int kw, int sh, int sw,
-                    int Hp, int Wp, int ldk, void *stream);
+                    int Hp, int Wp, int ldk, int split_plain, void *stream);
 
 /* Overlap-add scatter of a ConvTranspose2d computed as GEMM (vit_nlc.py:628-630,
  * 666-669), fused with de-normalisation x*std[c] + mean[c] (cra5_api.py:268-271) when

@@ -468,6 +468,12 @@ def test_tiled_patch_gather_scatter_matches_generic(dev, C):
     sm = ops.SplitMat.empty(72 * 144, K, dev, zero=True)
     ops.im2col(x.to(dev), 11, 10, 10, 10, mean=mean.to(dev), std=std.to(dev), out_split=sm)
     assert float((sm.to_float().cpu() - ref).abs().max()) <= 2 ** -21 * float(ref.abs().max()) + 2 ** -24
+    # reduced-precision mode: PLAIN rows = the hi plane, the K padding re-zeroed by the kernel (the buffer holds junk here)
+    sp = ops.SplitMat.empty(72 * 144, K, dev)
+    sp.data.fill_(0x3c00)
+    ops.im2col(x.to(dev), 11, 10, 10, 10, mean=mean.to(dev), std=std.to(dev), out_split=sp, out_plain=True)
+    assert sp.plain and torch.equal(sp.data[:, :K], _hi_plane(sm)[:, :K]) and torch.count_nonzero(sp.data[:, K:sp.Kp]) == 0
+    assert bool((sp.data[:, sp.Kp:] == 0x3c00).all())          # nothing written past the plain row
     back = ops.col2im(cols[:, :K], C, 11, 10, 10, 10, 72, 144, mean=mean.to(dev), std=std.to(dev))
     ref_back = torch.nn.functional.fold(ref.t()[None], (H, W), (11, 10), stride=(10, 10))[0]
     assert rmse(back, ref_back * std[:, None, None] + mean[:, None, None]) < 1e-6
