@@ -229,7 +229,8 @@ int cra5_window_attention_split_ws(const uint16_t *qkv_split, int qkv_kp, const 
  * adds the overlap pairs in fixed order: no [tokens][C*110] column matrix, no pass over it, deterministic, and
  * bit-identical to cra5_gemm_nt_split + cra5_col2im_f32.  Only this geometry (kh 11, kw 10, strides 10, W % 4 == 0,
  * Kp <= 8192); cra5_unembed_side_bytes returns 0 and the launcher CRA5_ERR_ARG for anything else - use the two-call
- * form then.  hi_only: the reduced-precision mode of cra5_gemm_nt_split. */
+ * form then.  hi_only: the reduced-precision mode of cra5_gemm_nt_split - bit 0 (1) hi-only products, | 2 the A rows are
+ * plain f16 rows, | 4 the weight is a packed plain [N][Kp] f16 matrix (bits 1 / 2 only with bit 0; see CRA5_GEMM_A_PLAIN). */
 size_t cra5_unembed_side_bytes(int C, int H, int W, int kh, int kw, int sh, int sw);
 int cra5_gemm_nt_split_unembed(const uint16_t *A, int lda_kp, const uint16_t *W_split, int ldw_kp, float *x,
                                float *side, size_t side_bytes, const float *mean, const float *stdv, int M, int Kp,

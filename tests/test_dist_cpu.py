@@ -193,3 +193,19 @@ def test_visible_gpu_count(monkeypatch):
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0,5")
     assert D.visible_gpu_count(8) == 3
     assert D.visible_gpu_count(4) == 2          # an entry that names no GPU ends the list, like the runtime's own rule
+
+
+def test_bench_committed_reference_reads_the_profile_of_its_own_precision():
+    """`roofline.committed_reference` comes from the newest committed rocprofv3 summary of the SAME arithmetic: the
+    fp32-accurate line must not pick up `rNN_f16_bench_exclusive_kernel_stats.csv` (it sorts after
+    `rNN_bench_exclusive_...` and holds half-length launches), and the reduced-precision line is priced against the
+    plain-f16 peak."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, root)
+    import bench
+    a, b = bench.rocprof_gemm_frac(), bench.rocprof_gemm_frac(f16=True)
+    assert a is not None and "_f16_" not in a["file"] and 0.2 < a["frac"] < 1.0
+    assert b is None or ("_f16_" in b["file"] and 0.05 < b["frac"] < 1.0)
+    if b is not None:
+        assert b["avg_launch_ms"] < a["avg_launch_ms"]
