@@ -230,13 +230,27 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     }
   }
   const float cexp = scale * 1.44269504088896340736f;  // scores -> log2 domain
+  // Reduced-precision mode: Q is pre-scaled by scale * log2 e ONCE (one more f16 rounding, inside the mode's tolerance)
+  // and the first score MFMA of a tile takes -m_run as its C operand, so the accumulator IS the exponent:
+  // p = exp2(acc), no v_fma per score (16 VALU fewer per key tile; the fp32-accurate form has no 16 registers to spare
+  // for the -m vector - DESIGN.md section 9).  VALU time is wall time on this chip's SIMDs.
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  if (HI) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qh[s][e] = (_Float16)((float)qh[s][e] * cexp);
+  }
+  const float cmax = HI ? 1.0f : cexp;   // tile max -> log2 domain (already there in the reduced-precision mode)
 
   f32x16 o[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = HI ? 0.f : -INFINITY, l_run = 0.f;   // (reduced precision: reference 0 until the first tile sets it)
 
   const int n_tiles = j1 - j0;   // key tiles of this work-group (all L / 32 of them but for the key-split leftover pass)
   uint4 sk0 = make_uint4(0u, 0u, 0u, 0u), sk1 = sk0, sv0 = sk0, sv1 = sk0;
@@ -325,10 +339,23 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], acc_, 0, 0, 0);         \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], acc_, 0, 0, 0);         \
       }                                                                                   \
-      acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], acc_, 0, 0, 0);           \
+      if (HI && st == 0) {                                                                \
+        CRA5_MFMA_FROM(acc_, kh, qh[0], negm);                                            \
+      } else {                                                                            \
+        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], acc_, 0, 0, 0);         \
+      }                                                                                   \
     }                                                                                     \
     DST = acc_;                                                                           \
   }
+  // D = A.B + C with C a DIFFERENT, persistent register tuple (the -m_run vector): as a builtin hipcc ties D to C and
+  // copies the 16 registers in front of every tile.  s_nop: C is written by VALU in the (rare) rescale branch, and no
+  // hazard wait states are inserted for inline asm; the K fragment's s_waitcnt is (operands of the asm statement).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRA5_MFMA_FROM(D, A, B, C) \
+  asm("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C))
+#else
+#define CRA5_MFMA_FROM(D, A, B, C) (D) = (C)
+#endif
 
   const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
   // V^T fragments (A operand: row d = l31, 8 keys per lane) come out of the ROW-MAJOR V image through
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   ({                                                                                      \
     float m_ = fmaxf(fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3])), fmaxf(fmaxf(S[4], S[5]), fmaxf(S[6], S[7]))); \
     float n_ = fmaxf(fmaxf(fmaxf(S[8], S[9]), fmaxf(S[10], S[11])), fmaxf(fmaxf(S[12], S[13]), fmaxf(S[14], S[15]))); \
-    CRA5_XHALF_MAX(fmaxf(m_, n_)) * cexp; /* cexp > 0: max commutes with the scale */      \
+    CRA5_XHALF_MAX(fmaxf(m_, n_)) * cmax; /* cexp > 0: max commutes with the scale */      \
   })
 #else
 // 16 scores -> their max in 8 VALU (v_max3_f32 tree) instead of 15 v_max_f32.  Plain C in the shape hipcc folds
@@ -379,7 +406,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     const float a_ = CRA5_MAX3(S[0], S[1], S[2]), b_ = CRA5_MAX3(S[3], S[4], S[5]), c_ = CRA5_MAX3(S[6], S[7], S[8]); \
     const float d_ = CRA5_MAX3(S[9], S[10], S[11]), e_ = CRA5_MAX3(S[12], S[13], S[14]);     \
     const float f_ = CRA5_MAX3(a_, b_, c_), g_ = CRA5_MAX3(d_, e_, S[15]);                   \
-    CRA5_XHALF_MAX(CRA5_MAX2_VALU(f_, g_)) * cexp; /* cexp > 0: max commutes with the scale */ \
+    CRA5_XHALF_MAX(CRA5_MAX2_VALU(f_, g_)) * cmax; /* cexp > 0: max commutes with the scale */ \
   })
 #endif
 
@@ -404,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // on the pad row and store nothing: one code path, no divergent barriers.
   // One key tile; the loop below is unrolled by two with the score registers swapping roles, so that tile j+1's
   // scores never have to be copied into tile j's registers (8 v_mov_b64 per tile).
-  auto key_tile = [&](const int j, const f32x16 &s_cur, f32x16 &s_next) __attribute__((always_inline)) {
+  auto key_tile = [&](const int j, f32x16 &s_cur, f32x16 &s_next) __attribute__((always_inline)) {
     const int kb = (j + 1) & 1, vb = j & 1;
     // (a wave whose 32 queries all lie past the end of the window - half of the fifth 128-query work-group of a
     // 576-token window - only stages and synchronises: its MFMAs would be taken from the other waves of its SIMD)
@@ -421,7 +448,39 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     // one of a window's 18; with the threshold it fires on the first tile or two.  (m_run = -inf at the start: the
     // difference is +inf, the branch is taken, alpha = exp2(-inf) = 0 scales the zero accumulators.)
     constexpr float DEFER_LOG2 = 8.0f;
-    if (!__all(mloc - m_run <= DEFER_LOG2)) {
+    // Reduced precision: s_cur is RELATIVE to m_run (the -m_run C operand of the score MFMAs).  shift(): move the
+    // reference by an f16-representable delta (any point near the maximum will do) - ONE MFMA adds it, exactly, to all
+    // 16 registers of a lane (A = e_0 rows: 1 in k-slot 0; B = -delta of the lane's query in k-slot 0).  Updating the
+    // C-operand vector by an MFMA keeps it an opaque accumulator tuple for hipcc (written element by element it is
+    // re-materialised in front of every tile: 16-31 v_mov per tile).
+    auto shift = [&](float delta, const bool rescale, f32x16 *also) __attribute__((always_inline)) {
+      delta = (float)(_Float16)fminf(fmaxf(delta, -60000.f), 60000.f);
+      if (rescale) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      }
+      m_run += delta;
+      half8 e0, bd;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        e0[e] = (_Float16)0.0f;
+        bd[e] = (_Float16)0.0f;
+      }
+      e0[0] = (_Float16)(h == 0 ? 1.0f : 0.0f);
+      bd[0] = (_Float16)(h == 0 ? -delta : 0.0f);
+      s_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bd, s_cur, 0, 0, 0);
+      negm = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bd, negm, 0, 0, 0);
+      if (also) *also = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bd, *also, 0, 0, 0);
+    };
+    if (HI) {
+      // the first tile of a segment sets the reference (either direction) from its max, known from the prologue; later
+      // tiles do NOT compute a max at all: see the overflow check behind the exponentials
+      if (j == 0) shift(mloc, false, nullptr);
+    } else if (!__all(mloc - m_run <= DEFER_LOG2)) {
       const float m_new = fmaxf(m_run, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
@@ -438,6 +497,41 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     float psum = 0.f;
     half8 ph[2], pl[2];
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (HI) {
+      // p = exp2(acc); the row sum is taken over the ROUNDED f16 values the PV MFMAs multiply (v_dot2c_f32_f16 with
+      // (1, 1): two scores per VALU, fp32 accumulate) - numerator and denominator see the same p.
+      // No per-tile max (11 VALU): the exponentials are taken against the standing reference and the row sum tells
+      // afterwards whether some p left the safe range (2^13; f16 holds 2^16) - then, and only then, the tile max is
+      // computed, O / l / the scores of this and the next tile are shifted and the exponentials redone.  A new record
+      // of that size among the first k keys is rare after the first tiles (the fp32-accurate form defers at 2^8).
+      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+      typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+      const half2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+      auto exps = [&]() __attribute__((always_inline)) {
+        psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          half2v hp[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hp[i] = half2v{(_Float16)__builtin_amdgcn_exp2f(s_cur[8 * t + 2 * i]), (_Float16)__builtin_amdgcn_exp2f(s_cur[8 * t + 2 * i + 1])};
+            psum = __builtin_amdgcn_fdot2(hp[i], ones, psum, false);
+          }
+          ph[t] = half8v{hp[0][0], hp[0][1], hp[1][0], hp[1][1], hp[2][0], hp[2][1], hp[3][0], hp[3][1]};
+        }
+      };
+      exps();
+      constexpr float P_SAFE = 8192.0f;
+      if (!__all(psum <= P_SAFE)) {          // (a NaN row sum takes the branch too and stays NaN: the range guard's business)
+        const float mrel = CRA5_TILE_MAX(s_cur);
+        shift(fmaxf(mrel, 0.f), true, &s_next);
+        exps();
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pl[t][e] = (_Float16)0.0f;
+    } else
     // p -> (hi, lo) with lo = p - f32(hi) as ONE v_fma_mix_f32 that reads the f16 half in place (no
     // v_cvt_f32_f16 + v_sub per element): 4 VALU per two scores instead of 7.  MFMA and VALU of the waves of a
     // SIMD do not overlap on this chip: every VALU removed here is wall time.  Only the
@@ -472,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
 #else   /* host pass: the same arithmetic without the inline asm (never executed) */
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(fmaf(s_cur[r], cexp, -m_new));
+      const float p = HI ? (float)(_Float16)__builtin_amdgcn_exp2f(s_cur[r]) : __builtin_amdgcn_exp2f(fmaf(s_cur[r], cexp, -m_new));
       psum += p;
       const _Float16 hi = (_Float16)p;
       const _Float16 lo = (_Float16)(p - (float)hi);
@@ -504,7 +598,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[0], ph[t], o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[1], ph[t], o[1], 0, 0, 0);
     }
-    mloc = CRA5_TILE_MAX(s_next);
+    if (!HI) mloc = CRA5_TILE_MAX(s_next);
     }
     // K(j+2) -> the buffer tile j's scores came from (last read before the previous barrier),
     // V(j+1) -> the other V buffer (past the end: stale data into buffers nobody reads);

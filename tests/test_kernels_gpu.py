@@ -326,6 +326,36 @@ def test_attention_split_softmax_spike(dev, boost):
     assert rmse(out, ref) < 2e-6
 
 
+@pytest.mark.parametrize("case", ["boost4", "boost0.5", "boost1", "low_start", "ramp"])
+def test_attention_hi_only_reference_point(dev, case):
+    """Reduced-precision attention (hi_only): the exponent's reference point lives in the score MFMA's C operand
+    (p = exp2(acc) with Q pre-scaled by scale * log2 e) and is moved by an MFMA when a tile's max is 2^8 above it.
+    Late dominant keys (as the fp32-accurate twin above), a first tile far BELOW zero (the first tile sets the
+    reference in either direction) and a steady ramp (many small moves) against float64 on the f16-rounded operands."""
+    H, W, C, heads = 8, 72, 64, 1
+    N = H * W
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(N, 3 * C, generator=g)
+    qkv[:, C:2 * C] *= 0.1
+    if case.startswith("boost"):
+        qkv[500, C:2 * C] = qkv[17, :C] * float(case[5:])
+    elif case == "low_start":
+        qkv[:, :C] = qkv[:, :C].abs()                # every score of the first key tiles ~ -60 (log2 domain: -87)
+        qkv[:64, C:2 * C] = -1.0
+    else:
+        qkv[:, :C] = qkv[:, :C].abs()
+        qkv[:, C:2 * C] = (torch.arange(N).float() / N * 3.0).reshape(N, 1)   # scores grow by ~0.2 log2 units per tile... x 64 d
+    x16 = qkv.half().double()
+    q, k, v = x16[:, :C], x16[:, C:2 * C], x16[:, 2 * C:]
+    ref = torch.softmax((q * C ** -0.5) @ k.t(), -1) @ v
+    qs = ops.split_f16(qkv.to(dev))
+    pad = ops.split_f16(torch.zeros(1, 3 * C, device=dev))
+    out = ops.window_attention_split(qs, pad, heads, H, W, H, W, out=torch.empty(N, C, device=dev), hi_only=True)
+    e, r = rmse(out, ref), float(torch.sqrt(torch.mean(ref ** 2)))
+    print(f"hi_only attention, {case}: rmse {e:.2e} (rms of the output {r:.2e})")
+    assert torch.isfinite(out).all() and e < 1.5e-3 * max(r, 0.05)
+
+
 def test_global_attention_hd72_ragged(dev):
     """648 tokens (not a multiple of the 32-key tile) and head dim 72: hyper-prior shape."""
     H, W, C, heads = 18, 36, 144, 2
