@@ -152,6 +152,34 @@ while time.time() < t_end:
         ops.window_attention_split(qs, ps, heads, H, W, wh, ww, out_split=out_s)
         e = rel(out_s.to_float(), outref.reshape(H * W, C)); worst["att"] = max(worst["att"], e)
         assert e < 1e-5, ("attention", H, W, wh, ww, heads, e)
+        # reduced-precision mode on the same case: hi planes only (split rows, then PLAIN rows: bit-identical), against
+        # float64 on the f16-rounded operands; a score scale of 1 / 3 / 8 walks the reference point of the exponentials
+        # through its rare paths (first tile below zero, a-posteriori overflow check + shift)
+        sc = float(rng.choice([1.0, 3.0, 8.0]))
+        qkv16 = qkv.clone(); qkv16[:, :C] *= sc
+        pad16 = padrow.clone(); pad16[:C] *= sc
+        full = pad16.half().double().repeat(nwr * wh, nwc * ww, 1)
+        full[:H, :W] = qkv16.half().double().reshape(H, W, 3 * C)
+        ref16 = torch.zeros(H, W, C, dtype=torch.float64)
+        for r in range(nwr):
+            for c in range(nwc):
+                blk = full[r * wh:(r + 1) * wh, c * ww:(c + 1) * ww].reshape(wh * ww, 3, heads, 64)
+                q, k, v = blk[:, 0].transpose(0, 1), blk[:, 1].transpose(0, 1), blk[:, 2].transpose(0, 1)
+                o = (torch.softmax(q @ k.transpose(1, 2) * 0.125, -1) @ v).transpose(0, 1).reshape(wh, ww, C)
+                hh, wv = min(wh, H - r * wh), min(ww, W - c * ww)
+                ref16[r * wh:r * wh + hh, c * ww:c * ww + wv] = o[:hh, :wv]
+        qs = ops.split_f16(qkv16.to(dev)); ps = ops.split_f16(pad16.to(dev).reshape(1, -1))
+        f_s = torch.empty(H * W, C, device=dev); f_p = torch.empty(H * W, C, device=dev)
+        ops.window_attention_split(qs, ps, heads, H, W, wh, ww, out=f_s, hi_only=True)
+        qp, pp = ops.SplitMat.empty(H * W, 3 * C, dev, zero=True), ops.SplitMat.empty(1, 3 * C, dev, zero=True)
+        for dst, src in ((qp, qs), (pp, ps)):
+            dst.data[:, : src.Kp] = src.data.view(src.rows, -1, 2, 32)[:, :, 0].reshape(src.rows, -1)
+            dst.plain = True
+        o_p = ops.SplitMat.empty(H * W, C, dev, zero=True)
+        ops.window_attention_split(qp, pp, heads, H, W, wh, ww, out=f_p, out_split=o_p, hi_only=True)
+        assert torch.equal(f_s, f_p), ("attention hi_only: plain rows != split rows", H, W, wh, ww, heads, sc)
+        e16 = rel(f_s, ref16.reshape(H * W, C)); worst["att_f16"] = max(worst.get("att_f16", 0.0), e16)
+        assert e16 < 2e-3, ("attention hi_only", H, W, wh, ww, heads, sc, e16)
         n_att += 1
     else:
         rows = int(rng.choice([1, 3, 64, 648, 1000])); D = int(rng.choice([64, 360, 1024]))
