@@ -532,6 +532,10 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only product path")
+    lws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if lws > torch.cuda.device_count() and os.environ.get("CRA5_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py: {lws} ranks on this node but {torch.cuda.device_count()} visible GPU(s) - one rank per GPU "
+                         "(CRA5_SHARE_GPU=1 lets ranks share a GPU: tests only, gloo gather)")
     # (N > 1: the rank is pinned to its GPU's NUMA share of the host cores inside init_from_env, BEFORE the process group
     # and the HIP runtime start their helper threads - ADVICE r3)
     rank, world, local = D.init_from_env("cuda", numa_bind=not args.no_numa_bind)
