@@ -288,3 +288,29 @@ def test_gpu_phase_slot_gate_orders_waiters_by_priority():
     for t in ts:
         t.join(timeout=10)
     assert peak[0] == 2
+
+
+def test_profiles_and_tools_readmes_match_the_directories():
+    """Every file under profiles/ is described in profiles/README.md (by name, by a `*` pattern, or as the `.txt` /
+    `.json` twin of a named file), every rNN_ file the README names exists, and tools/README.md names every script
+    under tools/ and no script that is gone."""
+    import fnmatch
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "profiles", "README.md")).read()
+    files = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f != "README.md")
+    pats = re.findall(r"`([^`\s]*\*[^`\s]*)`", txt)
+    stems = {f.rsplit(".", 1)[0] for f in files if f in txt}
+    missing = [f for f in files if f not in txt and not any(fnmatch.fnmatch(f, p) for p in pats)
+               and f.rsplit(".", 1)[0] not in stems]
+    assert not missing, f"profiles/ files the README does not describe: {missing}"
+    named = set(re.findall(r"`((?:r\d\d_)[A-Za-z0-9_.\-]+\.(?:json|csv|txt))`", txt))
+    assert not [m for m in named if m not in files], [m for m in named if m not in files]
+    t = open(os.path.join(root, "tools", "README.md")).read()
+    have = {f for f in os.listdir(os.path.join(root, "tools")) if os.path.isfile(os.path.join(root, "tools", f))}
+    have |= {"probes/" + f for f in os.listdir(os.path.join(root, "tools", "probes"))}
+    scripts = {f for f in have if f.endswith((".py", ".sh", ".hip")) and not f.startswith("_")}
+    assert not [f for f in scripts if f not in t], [f for f in scripts if f not in t]
+    table = t.split("| script |", 1)[1]
+    listed = set(re.findall(r"`([A-Za-z0-9_/]+\.(?:py|sh|hip))`", table)) - {"bench.py"}
+    assert not [f for f in listed if f not in have], [f for f in listed if f not in have]
