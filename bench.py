@@ -761,7 +761,11 @@ def main():
         own profiler runs, so bench.py reports the committed measurement, not a live one."""
         try:
             import glob
-            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+            import re
+            # rNN_traffic.json: the fp32-accurate mode; rNN_f16_traffic.json: the reduced-precision mode (plain rows)
+            pat = re.compile(r"r\d+_f16_traffic\.json$" if net.precision == "f16" else r"r\d+_traffic\.json$")
+            latest = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
+                            if pat.search(os.path.basename(p)))[-1]
             t = json.load(open(latest))
             return t["gemm_nt_split"]["avg_bytes_per_launch"]
         except Exception:  # noqa: BLE001
@@ -799,7 +803,7 @@ def main():
             out["roofline"] = {"kernel": "gemm_nt_split_kernel<2,4,{3|4},2> (192x256 / 256x256 tiles)", "bound": "mfma", "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": measured_traffic(),
                                "traffic_note": "bytes/launch at the L2<->fabric boundary (Infinity-Cache hits "
-                                               "included), newest profiles/r*_traffic.json; algorithmic minimum "
+                                               "included), newest profiles/rNN_traffic.json (rNN_f16_traffic.json in the reduced-precision mode); algorithmic minimum "
                                                "A + W + C = 55-230 MB/launch",
                                "peak_note": "dense f16 MFMA peak 2500 TF at the nominal 2.4 GHz / %d MFMA(s) per product.  The chip "
                                             "does not hold 2.4 GHz under this kernel: one round of 256x256 tiles (K = 8192) runs "

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the reduced-precision mode (BASELINE configs[4], CRA5_PRECISION=f16) under rocprofv3 - kernel stats of the
-# exclusive bench command and the MFMA-pipe PMC pass.   tools/profile_f16.sh [ROUND=r05] -> gpurun_out/ROUND/ROUND_f16_*
+# exclusive bench command, the MFMA-pipe PMC pass and the two HBM-traffic PMC passes.   tools/profile_f16.sh [ROUND=r05] -> gpurun_out/ROUND/ROUND_f16_*
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=${1:-r05}
@@ -38,5 +38,14 @@ for _, k, e in sorted(rows, reverse=True)[:12]:
 json.dump(out, open(f"{O}/{T}_f16_mfma_util.json", "w"), indent=1)
 PY
 rm -rf $O/pmc_f16
+# HBM-side bytes per kernel in this mode (one counter per pass, --kernel-trace only) -> ${T}_f16_traffic.json
+F=$R/gpurun_out/${T}_f16tr; rm -rf $F; mkdir -p $F
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $F/pmc_traffic_$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --exclusive --inflight 1 --no-kernel-timer $COMMON > $F/pmc_traffic_$c.log 2>&1 < /dev/null
+done
+cd $R
+python tools/traffic_summary.py $F $O/${T}_f16 "--precision f16" | tail -8
+rm -rf $F
 cut -c1-160 $O/${T}_f16_bench_exclusive.json
 python tools/kstats.py $O/${T}_f16_bench_exclusive_kernel_stats.csv 14

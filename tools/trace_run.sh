@@ -2,8 +2,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 T=${1:-r05t}
+X=${2:-}   # extra bench flags, e.g. "--precision f16"
 rm -rf $R/gpurun_out/$T; mkdir -p $R/gpurun_out/$T
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$T/prof -o bench -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --no-kernel-timer --no-matched-sample --no-clock-sampler > $R/gpurun_out/$T/bench.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$T/prof -o bench -- python $R/bench.py $X --steps 40 --warmup 5 --no-cpu-baseline --no-api-sample --no-f16-sample --no-best-case --no-kernel-timer --no-matched-sample --no-clock-sampler > $R/gpurun_out/$T/bench.log 2>&1 < /dev/null
 cd $R
 f=$(find gpurun_out/$T/prof -name '*kernel_trace.csv' | head -1)
 python tools/trace_gaps.py $f 0.5 | head -8 > gpurun_out/$T/concurrency.txt

@@ -12,6 +12,7 @@ import json
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+extra = (" " + sys.argv[3]) if len(sys.argv) > 3 else ""   # e.g. "--precision f16"
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
@@ -26,7 +27,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             w.writerow([k, n, round(a, 1), round(t, 1)])
     per[c] = {k: (n, a) for k, n, a, t in rows}
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) of "
-                 "`python bench.py --steps 1 --warmup 1 --exclusive --inflight 1 --no-kernel-timer` on 1 x MI355X "
+                 f"`python bench.py{extra} --steps 1 --warmup 1 --exclusive --inflight 1 --no-kernel-timer` on 1 x MI355X "
                  "(tools/profile_bench.sh, tools/traffic_summary.py)",
        "correction": "FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM "
                      "section); KB -> bytes; counted at the L2<->fabric boundary, Infinity-Cache hits included: an "
