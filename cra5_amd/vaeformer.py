@@ -861,11 +861,12 @@ class VAEformer(nn.Module):
                     hp = getattr(self._tls, "hp_stream", None)
                     if hp is None:
                         hp = self._tls.hp_stream = torch.cuda.Stream(device=self.device, priority=-1)
-                    with torch.cuda.stream(hp):
+                    with torch.cuda.stream(hp), ops.stream_scope():
                         yield
                         hp.synchronize()
                 else:
-                    yield
+                    with ops.stream_scope():   # (the launch stream of this thread, looked up once per phase)
+                        yield
                     torch.cuda.current_stream().synchronize()
             finally:
                 if sem is not None:
@@ -875,7 +876,8 @@ class VAEformer(nn.Module):
             return
         with self._gpu_lock:
             t1 = time.perf_counter() if log is not None else 0.0
-            yield
+            with ops.stream_scope():
+                yield
             torch.cuda.current_stream().synchronize()
             if log is not None:
                 log.append((threading.get_ident(), t0, t1, time.perf_counter()))
