@@ -195,7 +195,8 @@ def _dev(*ts):
 
 
 def _p(t):
-    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+    # (a plain int: every entry point declares its argtypes, ctypes converts int -> void * itself)
+    return None if t is None else t.data_ptr()
 
 
 def _row_stride(t):

@@ -481,7 +481,16 @@ class VAEformer(nn.Module):
     # ---- device plumbing ---------------------------------------------------------------
     @property
     def device(self):
-        return self.quant_conv.weight.device
+        d = self.__dict__.get("_dev")   # (cached: asked ~230 times per frame by the workspace lookups; _apply() resets it)
+        if d is None:
+            d = self.__dict__["_dev"] = self.quant_conv.weight.device
+        return d
+
+    def _apply(self, fn, *args, **kwargs):
+        try:
+            return super()._apply(fn, *args, **kwargs)
+        finally:
+            self.__dict__["_dev"] = None
 
     def _require_gpu(self):
         if self.device.type != "cuda":
@@ -495,7 +504,7 @@ class VAEformer(nn.Module):
         ws = getattr(self._tls, "ws", None)
         if ws is None:
             ws = self._tls.ws = {}
-        key = (name, tuple(shape), dtype, str(self.device))
+        key = (name, tuple(shape), dtype, self.device)
         b = ws.get(name)
         if b is None or b[0] != key:
             t = (torch.zeros if zero else torch.empty)(shape, device=self.device, dtype=dtype)
@@ -505,7 +514,7 @@ class VAEformer(nn.Module):
 
     def _derive(self, name, src, fn):
         """GEMM-ready re-layouts of weights, cached until the parameter changes."""
-        key = (src.data_ptr(), src._version, str(src.device))
+        key = (src.data_ptr(), src._version, src.device)
         d = self._derived.get(name)
         if d is None or d[0] != key:
             with self._derive_lock:
@@ -527,7 +536,7 @@ class VAEformer(nn.Module):
         ws = getattr(self._tls, "sws", None)
         if ws is None:
             ws = self._tls.sws = {}
-        key = (rows, K, str(self.device))
+        key = (rows, K, self.device)
         b = ws.get(name)
         if b is None or b[0] != key:
             b = (key, ops.SplitMat.empty(rows, K, self.device, zero=zero))
