@@ -372,6 +372,52 @@ def api_pipelined_sample(net, pipe, frames, inflight, n):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _job_dir():
+    """A directory every rank of THIS job agrees on (the error line's lock lives there): handed down by self_launch, or
+    derived from what an external launcher gives all its ranks alike (run id / port / the launcher's pid)."""
+    d = os.environ.get("CRA5_JOB_DIR")
+    if not d:
+        import tempfile
+        # under torch.distributed.run every rank shares the launcher's pid (one launch = one directory); a process
+        # nobody launched is its own job
+        launched = "TORCHELASTIC_RUN_ID" in os.environ
+        tag = "%s_%s_%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.environ.get("MASTER_PORT", "noport"),
+                            os.getppid() if launched else os.getpid())
+        d = os.path.join(tempfile.gettempdir(), "cra5_bench_" + "".join(c if c.isalnum() or c in "_-" else "_" for c in tag))
+    if not os.path.isdir(d):
+        os.makedirs(d, exist_ok=True)
+        if not os.environ.get("CRA5_JOB_DIR") and "TORCHELASTIC_RUN_ID" not in os.environ:
+            import atexit
+            import shutil
+            atexit.register(shutil.rmtree, d, True)          # a one-process job cleans up after itself
+    return d
+
+
+def error_line(exc, stage):
+    """A rank died before it could take part in the JSON line: print ONE parsable line - the first
+    failing rank's, whichever rank that is - with the contract's keys, `value` null, "error" and the traceback; the
+    launcher then ends the other ranks.  Returns True if this rank printed."""
+    import traceback
+    try:
+        fd = os.open(os.path.join(_job_dir(), "error_line.lock"), os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        os.close(fd)
+    except FileExistsError:
+        return False
+    except OSError:
+        pass                                      # no lock possible: better two lines than none
+    tb = "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))
+    line = {"metric": "ERA5 frames/s (721x1440x268) encode+decode", "value": None, "unit": "frames/s",
+            "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "higher_is_better": True,
+            "error": f"{type(exc).__name__}: {exc}", "failed_rank": int(os.environ.get("RANK", "0")),
+            "failed_local_rank": int(os.environ.get("LOCAL_RANK", "0")), "stage": stage,
+            "hostname": os.uname().nodename, "traceback": tb[-6000:]}
+    print(json.dumps(line), flush=True)
+    return True
+
+
+STAGE = ["startup"]     # where main() is (the error line names it)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
     torch.distributed.run (one process per GPU; standalone rendezvous on 127.0.0.1, port chosen by the launcher).  stdout / stderr are
@@ -387,7 +433,21 @@ def self_launch(n):
     # closing it again was a bind / close race between concurrent jobs); 127.0.0.1: the container hostname may not resolve
     cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
            f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env, stdin=subprocess.DEVNULL)
+    import shutil
+    import tempfile
+    env["CRA5_JOB_DIR"] = jd = tempfile.mkdtemp(prefix="cra5_bench_job_")
+    try:
+        rc = subprocess.call(cmd, env=env, stdin=subprocess.DEVNULL)
+        if rc != 0 and not (os.path.exists(os.path.join(jd, "error_line.lock")) or os.path.exists(os.path.join(jd, "line_printed"))):
+            # a rank died without reaching Python's exception machinery (signal, out-of-memory kill, launcher failure)
+            print(json.dumps({"metric": "ERA5 frames/s (721x1440x268) encode+decode", "value": None, "unit": "frames/s",
+                              "n_gpus": n, "higher_is_better": True, "failed_rank": None, "stage": "unknown",
+                              "error": f"the {n}-rank job exited with code {rc} and no rank reported a Python exception "
+                                       "(killed by a signal / the out-of-memory killer, or the launcher itself failed): "
+                                       "see stderr"}), flush=True)
+        return rc
+    finally:
+        shutil.rmtree(jd, ignore_errors=True)
 
 
 def dry_dist(args):
@@ -399,17 +459,25 @@ def dry_dist(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cpu = torch.device("cpu")
+    STAGE[0] = "preflight"
+    pre = D.preflight(cpu, args.inflight, min(args.frame_pool, args.steps))
+    STAGE[0] = "warm-up"
+    _test_failure_hook(rank)
     my = D.shard_frames(world * args.steps, rank, world)
     D.barrier()
+    STAGE[0] = "timed region"
     t0 = time.perf_counter()
     rows = [D.frame_stats(f, [[bytes([f % 251]) * (100 + f)], [bytes([(7 * f) % 251]) * (10 + f)]]) for f in my]
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0 + 1e-3 * (rank + 1), cpu)
+    mine = time.perf_counter() - t0 + 1e-3 * (rank + 1)
+    elapsed = D.max_over_ranks(mine, cpu)
     stats = D.gather_stats(rows, cpu)
     assert stats[:, 0].tolist() == list(range(world * args.steps)), "gathered stats do not cover the frame set"
     hosts = D.gather_objects(dict(D.host_report(), numa_bind=D.LAST_BIND))
+    per_rank = D.gather_objects(per_rank_line(rank, args.steps, mine, None, []))
     if rank == 0:
         print(json.dumps({"metric": "dry-dist (no GPU work)", "dry": True, "n_gpus": world, "steps": args.steps,
+                          "preflight": pre, "per_rank": per_rank,
                           "host_per_rank": [dict(h, cpus=[h["cpus"][0], h["cpus"][-1]] if h["cpus"] else []) for h in hosts],
                           "host_cpu_sets_disjoint": _disjoint([h["cpus"] for h in hosts]),
                           "stats_fields": list(D.STATS_FIELDS),
@@ -421,6 +489,22 @@ def dry_dist(args):
               flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+def _test_failure_hook(rank):
+    """tests/test_dist_cpu.py: CRA5_TEST_FAIL_RANK=r makes rank r die before the timed region (the error line's path)."""
+    r = os.environ.get("CRA5_TEST_FAIL_RANK")
+    if r is not None and int(r) == rank:
+        raise RuntimeError(f"injected failure on rank {rank} (CRA5_TEST_FAIL_RANK)")
+
+
+def per_rank_line(rank, steps, elapsed_own, clock, host_log):
+    """What one rank contributes to `per_rank`: its OWN frames/s over the timed region (the job's
+    `value` uses the slowest rank's time), the shader clock its GPU held, its host rANS phase times - so that a < N x
+    result can be attributed to a slow GPU, host contention or power."""
+    return {"rank": rank, "value": steps / elapsed_own if elapsed_own else None, "elapsed_s": elapsed_own,
+            "shader_clock": clock, "host_phase_ms": {k: v for k, v in host_phase_summary(host_log).items() if k != "note"},
+            "hostname": os.uname().nodename, "pid": os.getpid()}
 
 
 def _disjoint(sets):
@@ -477,9 +561,10 @@ def main():
                     help="extra untimed warm-up batches (2 x inflight frames each) until the batch time settles")
     ap.add_argument("--settle-min-batches", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", choices=("sample", "full", "only-full"), default="sample",
-                    help="sample (default): bounded ~20 s sample, extrapolated; full: one whole frame through the "
-                         "oracle (BASELINE configs[0], minutes); only-full: just that, no GPU run (prints its JSON)")
+    ap.add_argument("--cpu-baseline", choices=("sample", "full", "only-full"), default="full",
+                    help="full (default, round 6): ONE whole frame through the oracle on this box's host cores, after the GPU "
+                         "legs (BASELINE configs[0], ~1 min on 128 cores, ~20 GB of RAM); sample: bounded ~20 s sample, "
+                         "extrapolated; only-full: just the whole frame, no GPU run (prints its JSON)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (0 = physical cores)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-sample", type=int, default=29,
@@ -510,7 +595,11 @@ def main():
                     help="skip the entropy-matched weight-variant sample (`entropy_matched`, rank 0, N = 1)")
     ap.add_argument("--no-clock-sampler", action="store_true", help="no shader-clock sampler wave beside the timed region")
     ap.add_argument("--no-numa-bind", action="store_true",
-                    help="N > 1: do not pin a rank's threads to its GPU's NUMA node share of the host cores")
+                    help="do not pin a rank's threads to its GPU's NUMA node share of the host cores")
+    ap.add_argument("--numa-bind-single", choices=("on", "off"), default=os.environ.get("CRA5_NUMA_BIND_SINGLE", "on"),
+                    help="N = 1: bind the process to the GPU's NUMA node as the N > 1 ranks are (frame threads, rANS work and "
+                         "the pageable -> pinned copies of the API samples then run beside the GPU's root complex); the CPU "
+                         "baseline leg lifts the bind again")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "12")),
                     help="frames in flight per GPU (host rANS of one frame overlaps GPU work of the others)")
     args = ap.parse_args()
@@ -538,7 +627,9 @@ def main():
                          "(CRA5_SHARE_GPU=1 lets ranks share a GPU: tests only, gloo gather)")
     # (N > 1: the rank is pinned to its GPU's NUMA share of the host cores inside init_from_env, BEFORE the process group
     # and the HIP runtime start their helper threads - ADVICE r3)
-    rank, world, local = D.init_from_env("cuda", numa_bind=not args.no_numa_bind)
+    all_cpus = sorted(os.sched_getaffinity(0))       # (the CPU baseline leg lifts the bind again)
+    rank, world, local = D.init_from_env("cuda", numa_bind=not args.no_numa_bind,
+                                         bind_single=args.numa_bind_single == "on")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("CRA5_SHARE_GPU") == "1":
@@ -549,14 +640,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus}: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    numa = None
+    # N ranks share the node's host cores.  Pin this rank (its frame threads, its rANS work, its torch CPU pool)
+    # to its GPU's NUMA node, an equal share of that node's cores per rank on the node: pinned staging buffers
+    # are then allocated node-local and 8 x 12 frame threads do not migrate over both sockets.  (Round 6: at N = 1 too.)
+    numa = D.LAST_BIND
     if world > 1:
-        # N ranks share the node's host cores.  Pin this rank (its frame threads, its rANS work, its torch CPU pool)
-        # to its GPU's NUMA node, an equal share of that node's cores per rank on the node: pinned staging buffers
-        # are then allocated node-local and 8 x 12 frame threads do not migrate over both sockets.
-        numa = D.LAST_BIND
         share = len(os.sched_getaffinity(0)) if (numa and numa.get("bound")) else (os.cpu_count() or 8) // world
         torch.set_num_threads(max(1, share // 2))
+    # first-contact preflight: the job's first collective, every rank's free device memory / host
+    # CPUs / GPU identity; ALL ranks derive the same frames-in-flight figure from the gathered reports
+    STAGE[0] = "preflight"
+    pre = D.preflight(dev, args.inflight, min(args.frame_pool, args.steps))
+    if pre["inflight"] != args.inflight:
+        print(f"[bench] frames in flight lowered {args.inflight} -> {pre['inflight']}: {pre['lowered_because']}",
+              file=sys.stderr, flush=True)
+        args.inflight = pre["inflight"]
+    STAGE[0] = "model build"
 
     net = vaeformer_pretrained(quality=args.quality, pretrained=False)
     synth.load_synthetic(net, seed=7)
@@ -606,6 +705,8 @@ def main():
     net.gpu_slots = args.gpu_slots
     net.precision = args.precision
     # warm-up: W untimed steps (also builds the per-thread workspaces / derived weights)
+    STAGE[0] = "warm-up"
+    _test_failure_hook(rank)
     net.compress(frames[0])
     warm = pipe.map(round_trip, [frames[i % pool] for i in range(max(args.warmup, args.inflight))])
     # streams of the warm-up frames: the timed region codes the same tensors again and must reproduce them (sizes + CRC)
@@ -636,7 +737,7 @@ def main():
     # attributable lines: the shader clock the chip sustains over the timed region - short one-wave
     # probes launched every 5 ms by a host thread on their own stream - and the board power / sclk the driver exposes
     clk = None
-    if rank == 0 and not args.no_clock_sampler:
+    if not args.no_clock_sampler:            # (round 6: every rank samples its own GPU's clock -> `per_rank`)
         try:
             clk = ops.ClockSampler(dev)
             clk.probe()
@@ -651,6 +752,7 @@ def main():
     # another's: +15-25 % frames/s), which makes a single launch's start->stop duration
     # depend on what else is running; --exclusive serialises the phases instead.
     torch.cuda.synchronize()
+    STAGE[0] = "timed region"
     D.barrier()
     ops.TIMER = timer
     net.host_log = host_log = []
@@ -672,8 +774,10 @@ def main():
     if clk is not None:
         clk.stop()               # joins the probe thread; its last 50 us probe is covered by the sync below
     torch.cuda.synchronize()
+    elapsed_own = time.perf_counter() - t0           # this rank's K round trips (the job's time: after the barrier, max over ranks)
     D.barrier()
     elapsed = time.perf_counter() - t0
+    STAGE[0] = "after the timed region"
     _cra5_lib().cra5_clock_stamp(ctypes.c_void_p(region_marks.data_ptr() + 8), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     ops.TIMER = None
     net.host_log = None
@@ -700,6 +804,7 @@ def main():
     # every frame of the job is accounted for exactly once, on every rank
     assert stats[:, 0].tolist() == list(range(world * args.steps)), "gathered stats do not cover the frame set"
     hosts = D.gather_objects(dict(D.host_report(), numa_bind=D.LAST_BIND)) if world > 1 else None
+    per_rank = D.gather_objects(per_rank_line(rank, args.steps, elapsed_own, clocks["timed_region"], host_log))
 
     if rank == 0 and os.environ.get("CRA5_BENCH_STATS_OUT"):
         json.dump(stats.cpu().tolist(), open(os.environ["CRA5_BENCH_STATS_OUT"], "w"))
@@ -723,7 +828,7 @@ def main():
                    "frame": [C, 721, 1440], "weights": "deterministic synthetic (cra5_amd/synth.py seed 7)",
                    "parallelism": f"frame-sharded x{world}, weights replicated",
                    "distinct_frames_per_rank": pool, "frame_seeds_rank0": [seed_of_step[0], seed_of_step[-1]],
-                   "frames_in_flight_per_gpu": args.inflight,
+                   "frames_in_flight_per_gpu": args.inflight, "preflight": pre,
                    "host": {"frame_threads_total": args.inflight * world, "host_threads": os.cpu_count(),
                             "numa_bind_rank0": numa, "self_launched": os.environ.get("CRA5_SELF_LAUNCHED") == "1",
                             # N > 1: every rank's CPU mask after the bind, and how many of its threads (frame threads,
@@ -735,6 +840,8 @@ def main():
                                  "numa_node": (h.get("numa_bind") or {}).get("numa_node")} for h in hosts],
                             "cpu_sets_disjoint": None if hosts is None else _disjoint([h["cpus"] for h in hosts])}},
         "warmup_settle_frames": settle_frames,
+        # every rank's OWN frames/s, shader clock and host rANS phase times: attribution of a < N x result (item 5c)
+        "per_rank": per_rank,
         "clocks": clocks,
         "host_phase_ms": host_phase_summary(host_log),
         # frames 0 / 1 of the job (rank 0 owns them): product stream vs the stream the reference's Python wrote for the same tensor
@@ -998,31 +1105,53 @@ def main():
         except Exception as ex:  # noqa: BLE001
             result["api_pipelined"] = {"value": None, "error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # The reference's CPU path on THIS box's host cores, in THIS run, after every GPU leg so that a
+        # host busy with the oracle cannot touch `value`.  The pipeline's frame threads are idle by now; the NUMA bind of
+        # the GPU legs is lifted (the oracle gets every core of the box, as a CPU user of the reference would have).
+        STAGE[0] = "cpu baseline"
         try:
-            result["cpu_baseline"] = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(
-                args.quality, cpu_threads)
-            if result["cpu_baseline"].get("extrapolated"):
-                import glob
-                full = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_full.json")))
-                if full:
-                    # the committed WHOLE-frame run is the headline figure (the bounded sample's extrapolation
-                    # overstates the CPU by ~10 %); this run's sample sits beside it
-                    cb = json.load(open(full[-1])).get("cpu_baseline", {})
-                    live = result["cpu_baseline"]
-                    result["cpu_baseline"] = {
-                        "value": cb.get("value"), "unit": "frames/s", "cores": cb.get("cores"), "kind": "port",
-                        "physical_cores": live.get("physical_cores"), "hardware_threads": live.get("hardware_threads"),
-                        "cpu": live.get("cpu"),
-                        "sample": "pre-recorded whole frame (profiles/" + os.path.basename(full[-1]) + "): " + str(cb.get("sample")),
-                        "this_run_bounded_sample": {"value": live["value"], "extrapolated": True, "sample": live["sample"]}}
+            pipe.close()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            try:
+                D._pin_all_threads(all_cpus)
+            except OSError:
+                pass
+            live = (cpu_baseline_full if args.cpu_baseline == "full" else cpu_baseline)(args.quality, cpu_threads)
+            live["measured_in_this_run"] = True
+            live["box"] = os.uname().nodename
+            import glob
+            full = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_full.json")))
+            if full:
+                # an earlier round's whole-frame run on another box of the pool, for comparison only (never `value`)
+                cb = json.load(open(full[-1])).get("cpu_baseline", {})
+                live["whole_frame_committed"] = {"value": cb.get("value"), "cores": cb.get("cores"), "cpu": cb.get("cpu"),
+                                                 "file": "profiles/" + os.path.basename(full[-1]), "pre_recorded": True}
+            result["cpu_baseline"] = live
         except Exception as e:  # noqa: BLE001
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
+        try:
+            open(os.path.join(_job_dir(), "line_printed"), "w").close()
+        except OSError:
+            pass
     pipe.close()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    import faulthandler
+    faulthandler.enable()            # a rank killed by SIGSEGV / SIGABRT at least leaves its Python stack on stderr
+    try:
+        main()
+    except SystemExit as e:
+        # a refusal with a message (WORLD_SIZE mismatch, no GPU, ...) is a death before the timed region too; an integer
+        # code is the self-launcher handing the job's exit code through
+        if isinstance(e.code, str):
+            error_line(e, STAGE[0])
+        raise
+    except BaseException as e:  # noqa: BLE001
+        error_line(e, STAGE[0])
+        raise

@@ -122,8 +122,20 @@ class Cra5Error(RuntimeError):
 
 
 ERR_RANGE = -9     # CRA5_ERR_RANGE: a value does not fit the compact record type
+ERR_DESYNC = -10   # CRA5_ERR_DESYNC: the stream decoded to its end without returning the coder to its initial state
+
+
+class StreamDesyncError(Cra5Error):
+    """A rANS stream was decoded to the last symbol, but the coder did not come back to RANS64_L with every word
+    consumed: the (tables, indexes) the decoder used are not the encoder's, or the stream is damaged.  The symbols that
+    were decoded are NOT the coded ones.  (The reference's decoder has no such check and returns them:
+    rans_interface.cpp:215-284.)"""
 
 
 def check(rc, what):
+    if rc == ERR_DESYNC:
+        raise StreamDesyncError(
+            f"{what}: the stream decoded to its last symbol but the coder did not return to its initial state "
+            f"(status {rc}): the CDF indexes / tables are not the encoder's, or the stream is damaged", rc)
     if rc != 0:
         raise Cra5Error(f"{what} failed with status {rc}", rc)

@@ -292,7 +292,15 @@ int decode_impl(const uint8_t *enc, size_t len, const IdxT *indexes, size_t n, c
   Decoder d;
   const int rc = decoder_init(d, enc, len);
   if (rc) return rc;
-  return decode_symbols(d, indexes, n, t, out);
+  const int rs = decode_symbols(d, indexes, n, t, out);
+  if (rs) return rs;
+  // End-state check (the reference has none: rans_interface.cpp:215-284 hands back whatever it decoded).  rANS is a
+  // bijection: the encoder started from RANS64_L (Rans64EncInit) and wrote exactly the words the decoder needs, so
+  // after the last symbol of a stream decoded with the ENCODER's tables and indexes the state is RANS64_L again and
+  // no word is left.  Anything else means the symbols handed back are not the ones that were coded: a CDF index that
+  // differs from the encoder's (h_s evaluated on another platform), the wrong tables, or a damaged stream.
+  if (d.x != kRansL || d.p != d.end) return CRA5_ERR_DESYNC;
+  return CRA5_OK;
 }
 
 // ---- stateful objects: BufferedRansEncoder / RansDecoder.set_stream + decode_stream --------

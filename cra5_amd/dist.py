@@ -25,7 +25,7 @@ STATS_FIELDS = ("frame", "y_bytes", "z_bytes", "crc32", "n_escape")
 LAST_BIND = None    # what bind_rank_to_numa did for this process (bench.py reports it)
 
 
-def init_from_env(device_type="cuda", numa_bind=False):
+def init_from_env(device_type="cuda", numa_bind=False, bind_single=False):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as set by
     torch.distributed.run). Returns (rank, world, local_rank).  numa_bind: pin the rank to its GPU's NUMA share of the
     host cores first - before init_process_group and before the first HIP call of this function, so that the RCCL
@@ -34,7 +34,7 @@ def init_from_env(device_type="cuda", numa_bind=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if numa_bind and world > 1:
+    if numa_bind and (world > 1 or bind_single):     # bind_single: a 1-rank job binds to its GPU's node too (round 6)
         # ROCr re-pins its own helper threads (async-event loop) to ALL cpus unless told to inherit the creator's mask
         os.environ.setdefault("HSA_OVERRIDE_CPU_AFFINITY_DEBUG", "0")
         LAST_BIND = bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
@@ -348,3 +348,87 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)
+
+
+# ---- first-contact preflight of an N-rank job (round 6) ---------------------------------------------
+# The first N = 8 run on real hardware is also the first time RCCL, the NUMA bind, 8 x 12 frame threads and 8 GPUs meet.
+# Before the warm-up every rank reports what it found (a tiny collective of its own, free device memory, host CPUs in its
+# mask, whether the GPU it drives is the one the NUMA bind assumed) and ALL ranks derive the same frames-in-flight figure
+# from the gathered reports: a job that cannot keep the requested pipeline depth lowers it and says so in the JSON line
+# instead of dying in the warm-up (out of memory) or crawling (12 frame threads on 4 cores).
+
+GIB = float(1 << 30)
+# device memory of the frame pipeline (soak: 61.8 GiB with 12 in flight and a 24-frame pool):
+FRAME_BYTES = 268 * 721 * 1440 * 4                 # one fp32 ERA5 frame, 1.11 GB
+BASE_BYTES = int(3.6 * GIB)                        # weights fp32 + split-f16 copies + tables + slack
+PER_INFLIGHT_BYTES = int(2.2 * GIB) + FRAME_BYTES  # a frame thread's workspace (token buffers, patch matrix, side buffers) + its x_hat block
+MIN_INFLIGHT = 2
+
+
+def preflight_report(device, free_bytes=None):
+    """What THIS rank found (no collective).  free_bytes: override for tests / CPU dry runs (None on a CPU device = not
+    checked)."""
+    rep = {"rank": int(os.environ.get("RANK", "0")), "n_cpus": len(os.sched_getaffinity(0)),
+           "gpu_check": gpu_bind_check(), "free_bytes": free_bytes, "total_bytes": None, "device": str(device)}
+    fake = os.environ.get("CRA5_TEST_FREE_GIB")          # tests: "r:gib,r:gib" - a rank whose GPU is mostly taken
+    if fake:
+        for part in fake.split(","):
+            r, _, g = part.partition(":")
+            if int(r) == rep["rank"]:
+                rep["free_bytes"] = int(float(g) * GIB)
+    fake = os.environ.get("CRA5_TEST_N_CPUS")
+    if fake:
+        for part in fake.split(","):
+            r, _, c = part.partition(":")
+            if int(r) == rep["rank"]:
+                rep["n_cpus"] = int(c)
+    if rep["free_bytes"] is None and torch.device(device).type == "cuda":
+        free, total = torch.cuda.mem_get_info(device)
+        rep["free_bytes"], rep["total_bytes"] = int(free), int(total)
+    return rep
+
+
+def plan_inflight(reports, requested, pool_frames):
+    """Frames in flight for EVERY rank of the job (one figure: the ranks step in lock-step through barriers) from the
+    gathered reports.  Pure function (tested on CPU).  Returns (inflight, [reasons])."""
+    inflight, why = int(requested), []
+    for r in reports:
+        free = r.get("free_bytes")
+        if free is not None:
+            room = free - BASE_BYTES - pool_frames * FRAME_BYTES
+            fit = int(room // PER_INFLIGHT_BYTES)
+            if fit < inflight:
+                why.append(f"rank {r['rank']}: {free / GIB:.1f} GiB of device memory free -> room for {max(fit, 0)} frames in "
+                           f"flight beside the weights and a {pool_frames}-frame pool (requested {requested})")
+                inflight = min(inflight, fit)
+        ncpu = r.get("n_cpus")
+        if ncpu is not None and ncpu < inflight:
+            why.append(f"rank {r['rank']}: {ncpu} host CPUs in its mask < {inflight} frame threads (each frame's rANS phase "
+                       "wants a core of its own)")
+            inflight = max(MIN_INFLIGHT, min(inflight, ncpu))     # (few cores slow the job down, they do not stop it)
+    if inflight < MIN_INFLIGHT:
+        raise RuntimeError("preflight: the job cannot keep even %d frames in flight: %s" % (MIN_INFLIGHT, "; ".join(why)))
+    return inflight, why
+
+
+def preflight(device, requested, pool_frames, free_bytes=None):
+    """Collective (every rank calls it, after init_from_env, before any model memory exists).  1. a 40-byte all-gather -
+    the first RCCL traffic of the job, timed; 2. all_gather_object of the per-rank reports; 3. plan_inflight on the
+    gathered list (identical on every rank).  Returns the dict bench.py puts into `config.preflight`."""
+    import time
+    t0 = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    probe = gather_stats([[rank, 1, 2, 3, 4]], torch.device(device))      # int64[world, 5]: 40 bytes per rank
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if probe[:, 0].tolist() != list(range(world)):
+        raise RuntimeError(f"preflight: the 40-byte all-gather returned ranks {probe[:, 0].tolist()}, expected 0..{world - 1}")
+    t1 = time.perf_counter()
+    reports = sorted(gather_objects(preflight_report(device, free_bytes)), key=lambda r: r["rank"])
+    inflight, why = plan_inflight(reports, requested, pool_frames)
+    mism = [r["rank"] for r in reports if r["gpu_check"].get("match") is False]
+    return {"first_collective_s": t1 - t0, "seconds": time.perf_counter() - t0, "inflight_requested": int(requested),
+            "inflight": inflight, "lowered_because": why or None,
+            "gpu_numa_assumption_mismatch_ranks": mism or None,
+            "per_rank": [{"rank": r["rank"], "n_cpus": r["n_cpus"],
+                          "free_gib": None if r["free_bytes"] is None else round(r["free_bytes"] / GIB, 1),
+                          "gpu_check": r["gpu_check"]} for r in reports]}

@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import ERR_RANGE, Cra5Error
+from ._lib import ERR_RANGE, Cra5Error, StreamDesyncError
 from .entropy import EntropyBottleneck, GaussianConditional, get_scale_table
 
 __all__ = ["VAEformer", "config_for", "block_windows"]
@@ -1118,6 +1118,19 @@ class VAEformer(nn.Module):
         (rans_interface.cpp:120-160): the `n_escape` field of the per-frame stats row."""
         return list(getattr(self._tls, "n_escape", []))
 
+    @staticmethod
+    def _y_desync(e):
+        """The y stream decoded to its end with the wrong final coder state.  The decoder re-derives every CDF index
+        from ITS OWN h_s(z_hat) (vaeformer.py:378-400 in the reference): one index that differs from the encoder's -
+        h_s evaluated by another platform's float arithmetic, DESIGN.md section 2 - desynchronises everything after
+        it.  The reference decodes such a stream into a plausible-looking wrong frame; here it is an error."""
+        return StreamDesyncError(
+            "decompress: the y stream does not end in the coder's initial state.  The z stream decoded cleanly, so "
+            "the most likely cause is a hyper-prior CDF-index mismatch with the ENCODER's platform: this build's "
+            "h_s(z_hat) rounds at least one scale into a different table row than the build that wrote the stream "
+            "(a .bin written by the PyTorch reference or by another engine; DESIGN.md section 2).  A damaged y "
+            "stream or a different checkpoint looks the same.  Nothing was reconstructed", e.status)
+
     def _decompress_frame(self, y_string, z_string, shape, reconstruct, mean=None, std=None):
         """host: decode z | GPU: h_s, indexes | host: decode y | GPU: de-quantise (+ g_s)."""
         eb, gc = self.entropy_bottleneck, self.gaussian_conditional
@@ -1126,7 +1139,13 @@ class VAEformer(nn.Module):
         z_idx = eb._build_indexes((1, Cz, zh, zw))
         z_host = self._pinned("z_in", (Cz, zh * zw), torch.int32)
         t_host = time.perf_counter()
-        eb.decode_symbols(z_string, z_idx, out=z_host.numpy().reshape(-1))   # straight into pinned memory
+        try:
+            eb.decode_symbols(z_string, z_idx, out=z_host.numpy().reshape(-1))   # straight into pinned memory
+        except StreamDesyncError as e:
+            raise StreamDesyncError(
+                "decompress: the z stream does not end in the coder's initial state - it was not written with this "
+                "checkpoint's EntropyBottleneck tables (update() not run on the same weights?) or it is damaged; "
+                "nothing was reconstructed", e.status) from e
         if self.host_log is not None:
             self.host_log.append(("dec_z", time.perf_counter() - t_host))
         with self._gpu_phase(light=True):
@@ -1164,6 +1183,8 @@ class VAEformer(nn.Module):
             y_host = self._pinned("y_in16", tuple(means.shape), torch.int16)
             try:
                 gc.decode_symbols_compact(y_string, idx_h.numpy().reshape(-1), y_host.numpy().reshape(-1))
+            except StreamDesyncError as e:
+                raise self._y_desync(e) from e
             except Cra5Error as e:
                 if e.status != ERR_RANGE:
                     raise
@@ -1171,7 +1192,10 @@ class VAEformer(nn.Module):
                 idx_h = idx_h.to(torch.int32)
         if not compact:
             y_host = self._pinned("y_in", tuple(means.shape), torch.int32)
-            gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
+            try:
+                gc.decode_symbols(y_string, idx_h.numpy().reshape(-1), out=y_host.numpy().reshape(-1))
+            except StreamDesyncError as e:
+                raise self._y_desync(e) from e
         if self.host_log is not None:
             self.host_log.append(("dec_y", time.perf_counter() - t_host))
 

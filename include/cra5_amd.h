@@ -35,6 +35,9 @@ extern "C" {
 #define CRA5_ERR_ARG (-7)
 #define CRA5_ERR_UNAVAILABLE (-8) /* entry point not compiled into this build flavour */
 #define CRA5_ERR_RANGE (-9)     /* a value does not fit the compact record type: use the 32-bit entry point */
+#define CRA5_ERR_DESYNC (-10)   /* every symbol decoded, but the coder is not back at its initial state / words are left
+                                 * over: the indexes or tables are not the encoder's (or the stream is damaged) - the
+                                 * decoded symbols are NOT the coded ones.  One-shot decoders only (the whole stream). */
 
 int cra5_abi_version(void);
 
@@ -66,7 +69,8 @@ int cra5_rans_encode_resolved_compact(const uint32_t *start_range, const uint16_
 
 /* RansDecoder.decode_with_indexes (rans_interface.cpp:215-284). `out` has n slots.
  * Unlike the reference (which reads past the end of a corrupt stream) a truncated
- * stream returns CRA5_ERR_STREAM. */
+ * stream returns CRA5_ERR_STREAM, and a stream that decodes to the end WITHOUT returning the coder to its initial
+ * state (RANS64_L, every word consumed) returns CRA5_ERR_DESYNC: the reference hands back garbage silently there. */
 int cra5_rans_decode_with_indexes(const uint8_t *encoded, size_t len, const int32_t *indexes,
                                   size_t n, const int32_t *cdfs, int n_cdfs, int cdf_stride,
                                   const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out);

@@ -369,6 +369,42 @@ def stage_thin():
     print("thin done")
 
 
+THIN_FLIP_SEED = 2   # rounds 1-4's frame a: the product's h_s rounds ONE of its 165 888 scales into the neighbouring table row
+                     # (within 1e-5 of the boundary) - the documented cross-implementation flip case, kept as a fixture of
+                     # its own (round 6) beside the agreeing frames a (seed 135) and b (seed 162)
+
+
+def stage_thin_flip():
+    net = build_thin()
+    load_synth(net, seed=7)
+    x = synth.synth_frame(8, seed=THIN_FLIP_SEED).unsqueeze(0)
+    o = run_e2e(net, x, synth_yhat(16, 5), step_lat=37, step_img=1009, tag="thin_flip", full_ints=True)
+    o["x_seed"] = np.array([THIN_FLIP_SEED])
+    np.savez_compressed(os.path.join(HERE, "thin_e2e_flip.npz"), **o)
+    print("thin_flip done")
+
+
+def stage_thin_cands_pack():
+    """tests/golden/_cand/thin_cand_*.npz (scratch, stage thin_cands) -> ONE committed fixture thin_cands.npz: the
+    reference's integers of 36 thin frames (z symbols, CDF indexes, y symbols), from which the test rebuilds the streams
+    the reference's compress() writes (coder on the reference's integers == reference-python-written stream, pinned in
+    tests/test_reference_streams.py) and checks which of them decode on the product and which must be refused."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "_cand", "thin_cand_*.npz")),
+                   key=lambda f: int(os.path.basename(f)[len("thin_cand_"):-4]))
+    seeds, z, idx, sym = [], [], [], []
+    for f in files:
+        g = np.load(f)
+        seeds.append(int(os.path.basename(f)[len("thin_cand_"):-4]))
+        assert np.abs(g["z_sym"]).max() < 32768
+        z.append(g["z_sym"].reshape(-1).astype(np.int16))
+        idx.append(g["idx_full"].astype(np.int8))
+        sym.append(g["sym_full"].astype(np.int16))
+    np.savez_compressed(os.path.join(HERE, "thin_cands.npz"), seeds=np.array(seeds), z_sym=np.stack(z),
+                        idx_full=np.stack(idx), sym_full=np.stack(sym))
+    print("packed", len(seeds), "candidate frames")
+
+
 def stage_full():
     net = VAEformer(268).eval()
     load_synth(net, seed=7)
@@ -680,6 +716,6 @@ if __name__ == "__main__":
     ap.add_argument("--stage", nargs="+", default=["small", "thin"])
     a = ap.parse_args()
     for s in a.stage:
-        dict(small=stage_small, thin=stage_thin, thin_search=stage_thin_search, thin_cands=stage_thin_cands, thin2=stage_thin2, full=stage_full, full159=stage_full159, stats=stage_stats,
+        dict(small=stage_small, thin=stage_thin, thin_flip=stage_thin_flip, thin_cands_pack=stage_thin_cands_pack, thin_search=stage_thin_search, thin_cands=stage_thin_cands, thin2=stage_thin2, full=stage_full, full159=stage_full159, stats=stage_stats,
              cnn=stage_cnn, cnn_relu=stage_cnn_relu, ints=stage_ints, thin_matched=stage_thin_matched,
              thin64=lambda: stage_fp64("thin"), full64=lambda: stage_fp64("full"))[s]()

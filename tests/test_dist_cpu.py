@@ -209,3 +209,89 @@ def test_bench_committed_reference_reads_the_profile_of_its_own_precision():
     assert b is None or ("_f16_" in b["file"] and 0.05 < b["frac"] < 1.0)
     if b is not None:
         assert b["avg_launch_ms"] < a["avg_launch_ms"]
+
+
+# ---- round 6: first-contact hardening of the N-rank job -------------------------------------------------
+
+
+def _dry(n, extra_env=None, steps=4, timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                            "MASTER_PORT", "LOCAL_WORLD_SIZE", "CRA5_JOB_DIR")}
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", "1",
+                        "--dry-dist"], cwd=root, env=env, capture_output=True, text=True, timeout=timeout,
+                       stdin=subprocess.DEVNULL)
+    return p, [l for l in p.stdout.split("\n") if l.startswith("{")]
+
+
+def test_plan_inflight_pure():
+    """One frames-in-flight figure for the whole job from the gathered per-rank reports."""
+    ok = [dict(rank=r, free_bytes=int(280 * D.GIB), n_cpus=32) for r in range(8)]
+    assert D.plan_inflight(ok, 12, 8) == (12, [])
+    tight = [dict(r) for r in ok]
+    tight[3]["free_bytes"] = int(30 * D.GIB)          # somebody else's process sits on rank 3's GPU
+    n, why = D.plan_inflight(tight, 12, 8)
+    room = 30 * D.GIB - D.BASE_BYTES - 8 * D.FRAME_BYTES
+    assert n == int(room // D.PER_INFLIGHT_BYTES) and 2 <= n < 12 and len(why) == 1 and why[0].startswith("rank 3")
+    few = [dict(r) for r in ok]
+    few[6]["n_cpus"] = 5                              # a cgroup that leaves rank 6 five CPUs
+    n, why = D.plan_inflight(few, 12, 8)
+    assert n == 5 and "rank 6" in why[0]
+    none = [dict(rank=0, free_bytes=None, n_cpus=None)]          # CPU dry run: nothing to check
+    assert D.plan_inflight(none, 12, 8) == (12, [])
+    import pytest
+    dead = [dict(rank=0, free_bytes=int(4 * D.GIB), n_cpus=64)]
+    with pytest.raises(RuntimeError, match="cannot keep even"):
+        D.plan_inflight(dead, 12, 24)
+    # the 12-in-flight pipeline of the 1-GPU bench (24-frame pool) fits the soak's 61.8 GiB figure with room to spare
+    need = D.BASE_BYTES + 24 * D.FRAME_BYTES + 12 * D.PER_INFLIGHT_BYTES
+    assert 55 * D.GIB < need < 75 * D.GIB
+
+
+def test_eight_rank_preflight_lowers_inflight_and_reports_per_rank():
+    """8 gloo ranks: the preflight's 40-byte all-gather, the gathered reports, ONE frames-in-flight figure for all ranks
+    when one rank's GPU has little memory free, and a `per_rank` row from every rank."""
+    import json
+    p, lines = _dry(8, {"CRA5_TEST_FREE_GIB": "3:30,5:250", "CRA5_INFLIGHT": "12",
+                        "CRA5_TEST_N_CPUS": ",".join(f"{r}:32" for r in range(8))}, steps=8)   # (as on a 2 x 64-core node)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    pre = d["preflight"]
+    assert pre["inflight_requested"] == 12 and 2 <= pre["inflight"] < 12
+    assert pre["lowered_because"] and pre["lowered_because"][0].startswith("rank 3")
+    assert [r["rank"] for r in pre["per_rank"]] == list(range(8))
+    assert pre["per_rank"][3]["free_gib"] == 30.0 and pre["per_rank"][5]["free_gib"] == 250.0
+    assert pre["first_collective_s"] >= 0
+    assert sorted(r["rank"] for r in d["per_rank"]) == list(range(8))
+    assert all(r["value"] and r["value"] > 0 and "host_phase_ms" in r and "shader_clock" in r for r in d["per_rank"])
+
+
+def test_eight_rank_job_with_a_dying_rank_prints_one_error_line():
+    """A rank that dies before the timed region: the job's stdout is ONE parsable JSON line with "error", the failing
+    rank and its traceback; the exit code is non-zero (the driver records the failure instead of a missing line)."""
+    import json
+    p, lines = _dry(8, {"CRA5_TEST_FAIL_RANK": "5"}, steps=8)
+    assert p.returncode != 0
+    assert len(lines) == 1, p.stdout + p.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 8 and d["failed_rank"] == 5 and d["stage"] == "warm-up"
+    assert "injected failure on rank 5" in d["error"] and "RuntimeError" in d["traceback"] and "_test_failure_hook" in d["traceback"]
+
+
+def test_single_rank_refusal_is_an_error_line_too():
+    """`--gpus 2` under a launcher that says WORLD_SIZE=1: refused (as before) AND stdout carries the error line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    env.pop("CRA5_JOB_DIR", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--dry-dist"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300, stdin=subprocess.DEVNULL)
+    assert p.returncode != 0
+    lines = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1 and "WORLD_SIZE=1" in json.loads(lines[0])["error"]

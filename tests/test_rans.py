@@ -397,3 +397,110 @@ def test_compact_records_write_and_read_the_same_streams(seed):
         ops.rans_decode_compact(big_stream, idx.astype(np.uint8), cdf, lens, offs, out16)
     assert ei.value.status == ERR_RANGE
     assert np.array_equal(ops.rans_decode(big_stream, idx, cdf, lens, offs), sym_big)     # the 32-bit route reads it
+
+
+# ---- round 6: a desynchronised stream is an error, not a picture -----------------------------------
+# rans_interface.cpp:215-284 (the reference's decoder) hands back whatever symbols fall out of a stream decoded with
+# indexes that are not the encoder's; the product's one-shot decoders check that the coder is back at RANS64_L with every
+# word consumed (CRA5_ERR_DESYNC -> StreamDesyncError).
+
+
+def _gaussian_like_case(rng, n):
+    cdf, lens, offs = _random_tables(rng, 6, 40)
+    idx = rng.integers(0, cdf.shape[0], size=n).astype(np.int32)
+    sym = rng.integers(-30, 30, size=n).astype(np.int32)
+    return cdf, lens, offs, idx, sym
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_one_flipped_index_is_refused(seed):
+    from cra5_amd._lib import StreamDesyncError
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(200, 5000))
+    cdf, lens, offs, idx, sym = _gaussian_like_case(rng, n)
+    s = ops.rans_encode(sym, idx, cdf, lens, offs)
+    assert np.array_equal(ops.rans_decode(s, idx, cdf, lens, offs), sym)
+    n_desync = 0
+    for k in rng.integers(0, n, size=12):
+        bad = idx.copy()
+        others = [r for r in range(cdf.shape[0]) if r != idx[k] and not np.array_equal(cdf[r], cdf[idx[k]])]
+        bad[k] = others[int(rng.integers(0, len(others)))]
+        # the desynchronised tail either runs into an impossible symbol / the end of the stream (CRA5_ERR_STREAM) or
+        # decodes "successfully" into garbage - which the end-state check turns into CRA5_ERR_DESYNC.  Never symbols.
+        with pytest.raises(Cra5Error) as ei:
+            ops.rans_decode(s, bad, cdf, lens, offs)
+        n_desync += isinstance(ei.value, StreamDesyncError)
+        # the compact-record decoder (the frame path's) behaves the same
+        with pytest.raises(Cra5Error):
+            ops.rans_decode_compact(s, bad.astype(np.uint8), cdf, lens, offs, np.zeros(n, np.int16))
+        # the oracle restates the REFERENCE: it returns symbols (wrong ones) or a stream error, it has no end-state check
+    del n_desync   # (how often it is the END-STATE check that catches it: test_reference_decoder_semantics_are_silent_garbage)
+
+
+def test_end_state_check_trailing_and_missing_words():
+    from cra5_amd._lib import ERR_DESYNC, StreamDesyncError
+    rng = np.random.default_rng(7)
+    cdf, lens, offs, idx, sym = _gaussian_like_case(rng, 1000)
+    s = ops.rans_encode(sym, idx, cdf, lens, offs)
+    with pytest.raises(StreamDesyncError) as ei:
+        ops.rans_decode(s + b"\0\0\0\0", idx, cdf, lens, offs)           # a word nobody coded
+    assert ei.value.status == ERR_DESYNC
+    with pytest.raises(StreamDesyncError):
+        ops.rans_decode(s, idx[:-1], cdf, lens, offs)                    # one symbol short: state not back at RANS64_L
+    with pytest.raises(Cra5Error):
+        ops.rans_decode(s, np.concatenate([idx, idx[:1]]), cdf, lens, offs)   # one symbol too many
+    # the empty stream is exactly the flushed initial state
+    e = np.zeros(0, np.int32)
+    assert ops.rans_decode(ops.rans_encode(e, e, cdf, lens, offs), e, cdf, lens, offs).size == 0
+    with pytest.raises(StreamDesyncError):
+        ops.rans_decode(s, e, cdf, lens, offs)                           # symbols left in the stream
+
+
+def test_own_streams_never_trip_the_end_state_check():
+    """Soak: 400 random streams (empty to 20 k symbols, escapes with 1-8 nibble payloads, every row width) through the
+    one-shot, compact, resolved and batch routes - the check is silent on every stream this coder wrote."""
+    rng = np.random.default_rng(11)
+    for k in range(400):
+        cdf, lens, offs = _random_tables(rng, int(rng.integers(1, 9)), int(rng.integers(3, 200)))
+        n = int(rng.integers(0, 20000)) if k % 10 == 0 else int(rng.integers(0, 600))
+        idx = rng.integers(0, cdf.shape[0], size=n).astype(np.int32)
+        sym = rng.integers(-100, 100, size=n).astype(np.int32)
+        if k % 4 == 0 and n:
+            sym[::7] = rng.integers(-(1 << 27), 1 << 27, size=sym[::7].size)
+        s = ops.rans_encode(sym, idx, cdf, lens, offs)
+        assert np.array_equal(ops.rans_decode(s, idx, cdf, lens, offs), sym)
+        if n and np.abs(sym).max() < 32768:
+            out = np.zeros(n, np.int16)
+            ops.rans_decode_compact(s, idx.astype(np.uint8), cdf, lens, offs, out)
+            assert np.array_equal(out, sym)
+
+
+def test_reference_decoder_semantics_are_silent_garbage():
+    """What the check replaces.  On the codec's own Gaussian tables (escapes rare, every cumulative value lands in a real
+    bin) the oracle - a restatement of rans_interface.cpp:215-284, which has no end-state check - decodes a stream with ONE
+    neighbouring-row index (the cross-platform h_s flip of DESIGN.md section 2) into wrong symbols without complaint; the
+    product refuses every such stream, and mostly it is the end-state check (CRA5_ERR_DESYNC) that does."""
+    from cra5_amd._lib import StreamDesyncError
+    cdf, ln, off = [t.numpy() for t in R.gc_tables(R.get_scale_table(), cbind.pmf_to_cdf)]
+    table = R.get_scale_table().numpy()
+    rng = np.random.default_rng(3)
+    silent = caught_by_end_state = cases = 0
+    for _ in range(20):
+        n = 3000
+        idx = rng.integers(0, 64, size=n).astype(np.int32)
+        sym = np.rint(rng.standard_normal(n) * table[idx]).astype(np.int32)
+        s = ops.rans_encode(sym, idx, cdf, ln, off)
+        bad = idx.copy()
+        k = int(rng.integers(0, n // 2))
+        bad[k] = idx[k] + 1 if idx[k] < 63 else idx[k] - 1          # one step in the scale table
+        cases += 1
+        try:
+            got = cbind.rans_decode(s, bad, cdf, ln, off).numpy()
+            silent += int(not np.array_equal(got, sym))
+        except Exception:  # noqa: BLE001 - the oracle refuses streams it would read past
+            pass
+        with pytest.raises(Cra5Error) as ei:
+            ops.rans_decode(s, bad, cdf, ln, off)
+        caught_by_end_state += isinstance(ei.value, StreamDesyncError)
+    print(f"{cases} one-index flips: reference semantics silent garbage {silent}, product end-state check {caught_by_end_state}")
+    assert silent >= cases // 2 and caught_by_end_state >= cases // 4     # (the others run out of words: CRA5_ERR_STREAM)
