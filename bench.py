@@ -365,8 +365,12 @@ def api_pipelined_sample(net, pipe, frames, inflight, n):
                     "double staging per in-flight frame, H2D / D2H of one frame under the other frames' GPU and rANS phases; "
                     "encode_fps / decode_fps: the two batch calls one after the other (round_trip_fps = n / (t_encode + "
                     "t_decode)); `value` = round_trip_streamed_fps: roundtrip_batch, every frame host array -> .bin -> host "
-                    "consumer in one pipeline (the PCIe-inclusive counterpart of the line's device-resident `value`); a "
-                    "1.11 GB frame each way caps either direction at ~50 frames/s on PCIe Gen5 x16"})
+                    "consumer in one pipeline (the PCIe-inclusive counterpart of the line's device-resident `value`).  "
+                    "Round 6: ONE frame per direction on the link at a time (api.link_serial) - the link itself runs 57 GB/s "
+                    "= 51 frames/s either way and 97 GB/s both ways at once (profiles/r06_link_probe.txt), so encode / decode "
+                    "are link-bound near 51 and the streamed round trip is bound by the GPU (`value`) with H2D transfers "
+                    "stretched to ~31 ms under concurrent D2H + kernels (profiles/r06_api_phase_probe.txt)",
+            "link_serial": bool(api.link_serial)})
         return res
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -589,7 +593,7 @@ def main():
                     help="skip the short reduced-precision sample (`precision_f16`: BASELINE configs[4] on this GPU, rank 0, N = 1)")
     ap.add_argument("--no-api-sample", action="store_true",
                     help="skip the reference-named single-frame API sample (`api_single_frame`, rank 0, N = 1)")
-    ap.add_argument("--api-frames", type=int, default=36,
+    ap.add_argument("--api-frames", type=int, default=72,
                     help="frames of the pipelined PCIe-inclusive API sample (`api_pipelined`, rank 0, N = 1)")
     ap.add_argument("--no-matched-sample", action="store_true",
                     help="skip the entropy-matched weight-variant sample (`entropy_matched`, rank 0, N = 1)")

@@ -58,6 +58,15 @@ class cra5_api:
         self.local_root = local_root or f'{os.getcwd()}/data'
         # batch methods: host threads per frame copy between pageable and pinned memory (1 = one numpy copy on the frame thread)
         self.batch_copy_threads = int(os.environ.get("CRA5_BATCH_COPY_THREADS", "1"))
+        # batch methods: ONE frame per direction on the host link at a time (round 6).  Twelve frame threads that all
+        # issue their 1.11 GB H2D at once share the link - every frame lands after 12 transfer times, the GPU idles
+        # until then and the frames then queue for it in a convoy; one at a time, the first frame lands after one
+        # transfer time and the GPU starts while the next frame is on the wire.  The link itself runs 57 GB/s in either
+        # direction and 97 GB/s both ways at once (profiles/r06_link_probe.txt), so H2D and D2H get a gate each.
+        import threading
+        self.link_serial = True
+        self._link_gate = {"h2d": threading.Lock(), "d2h": threading.Lock()}
+        self.phase_log = None       # a list: (frame tag, phase, t_start, t_end) per batch-path phase (tools/api_phase_probe.py)
         self._era5 = None
         if weights is not None:
             self.net = weights.eval().to(self.device)
@@ -333,15 +342,47 @@ class cra5_api:
         if self.batch_copy_threads > 1 and arr.dtype == np.float32 and arr.flags["C_CONTIGUOUS"]:
             # a small team per frame (csrc/runtime.hip): chunk c + 1 is memcpy'd while the DMA engine moves chunk c - the
             # frame is on the device after max(memcpy / team, PCIe) instead of memcpy + PCIe
-            return ops.copy_h2d_staged(net._buf("api_x_dev", tuple(arr.shape)), arr, pin, threads=self.batch_copy_threads)
+            with self._link("h2d"):
+                return ops.copy_h2d_staged(net._buf("api_x_dev", tuple(arr.shape)), arr, pin, threads=self.batch_copy_threads)
         # host memcpy (+ dtype conversion) by numpy on THIS thread, GIL released: torch's copy_ fans one 1.11 GB copy out
         # over every core of the box (128 threads: 11 GB/s, one thread: 24 GB/s - tools/api_host_probe.sh) and the
         # twelve frame threads then fight over them; twelve single-threaded copies run side by side
+        t0 = time.perf_counter()
         np.copyto(pin.numpy(), arr, casting="same_kind")
+        self._log("stage_in_memcpy", t0)
         src = pin
         xdev = net._buf("api_x_dev", tuple(src.shape))
-        xdev.copy_(pin, non_blocking=True)              # async H2D on this frame's stream
+        with self._link("h2d"):
+            xdev.copy_(pin, non_blocking=True)              # async H2D on this frame's stream
+            if self.link_serial:
+                torch.cuda.current_stream().synchronize()   # the gate is held until the frame has landed
         return xdev
+
+    def _log(self, phase, t0):
+        if self.phase_log is not None:
+            import threading
+            self.phase_log.append((threading.get_ident(), phase, t0, time.perf_counter()))
+
+    def _link(self, direction):
+        """Context manager: this thread's turn on the host link in `direction` ("h2d" / "d2h"); logs wait + transfer."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def turn():
+            t0 = time.perf_counter()
+            if self.link_serial:
+                self._link_gate[direction].acquire()
+            t1 = time.perf_counter()
+            try:
+                yield
+            finally:
+                if self.link_serial:
+                    self._link_gate[direction].release()
+                if self.phase_log is not None:
+                    import threading
+                    self.phase_log.append((threading.get_ident(), direction + "_wait", t0, t1))
+                    self.phase_log.append((threading.get_ident(), direction, t1, time.perf_counter()))
+        return turn()
 
     def _encode_one(self, ts, arr, save_root, write=True):
         """One frame of the batch encode on the calling frame thread (its stream, its pinned / device buffers)."""
@@ -355,12 +396,14 @@ class cra5_api:
             # the frame has landed BEFORE this thread queues for a GPU-phase slot: a slot held while its stream waits 20 ms
             # for the PCIe transfer is a third of the chip's concurrency gone (encode_era5_batch: 38 -> frames/s)
             torch.cuda.current_stream().synchronize()
+            t_c = time.perf_counter()
             try:
                 y_str, z_str = self.net._compress_frame(x=x, mean=self._mean_flat, std=self._std_flat)
             except FloatingPointError:
                 self._require_finite(probe)     # a non-finite INPUT is the caller's ValueError, as before
                 raise
             self._require_finite(probe)
+            self._log("compress", t_c)
         output = {"strings": [[y_str], [z_str]], "z_shape": torch.Size([self.net.Hz, self.net.Wz])}
         t2 = time.time()
         file_url = f'{save_root}/{ts.split("-")[0]}/{ts}.bin'
@@ -387,21 +430,41 @@ class cra5_api:
         H, W = self.net.cfg['img_size']
         lstrings, shape = self._read_bin(path)
         with torch.no_grad():
+            t_d = time.perf_counter()
             x_hat = self.net._decompress_frame(lstrings[0][0], lstrings[1][0], shape, True,
                                                mean=self._mean_flat if denorm else None,
                                                std=self._std_flat if denorm else None)
+            self._log("decompress", t_d)
             pin = self.net._pinned("api_x_out", (C, H, W), torch.float32)
             if sink is None and out is not None and self.batch_copy_threads > 1:
-                ops.copy_d2h_staged(out[i], x_hat.reshape(C, H, W), pin, threads=self.batch_copy_threads)
+                with self._link("d2h"):
+                    ops.copy_d2h_staged(out[i], x_hat.reshape(C, H, W), pin, threads=self.batch_copy_threads)
                 return out[i]
-            pin.copy_(x_hat, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-        if sink is not None:
-            return sink(i, pin.numpy())
-        if out is not None:
-            np.copyto(out[i], pin.numpy())
-            return out[i]
-        return pin.numpy().copy()
+            with self._link("d2h"):
+                pin.copy_(x_hat, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+        t_s = time.perf_counter()
+        try:
+            if sink is not None:
+                return sink(i, pin.numpy())
+            if out is not None:
+                np.copyto(out[i], pin.numpy())
+                return out[i]
+            return pin.numpy().copy()
+        finally:
+            self._log("consume", t_s)
+
+    def _check_out(self, out, n):
+        """`out=` of the batch methods: the C memcpy / DMA behind it writes n x C x H x W float32 values, so anything else
+        is refused here with a ValueError (not an assert that `python -O` drops - ADVICE r5)."""
+        if out is None:
+            return
+        C = self.net.cfg['out_chans']
+        H, W = self.net.cfg['img_size']
+        if not isinstance(out, np.ndarray) or out.dtype != np.float32 or tuple(out.shape) != (n, C, H, W) \
+                or not out.flags["C_CONTIGUOUS"] or not out.flags["WRITEABLE"]:
+            raise ValueError(f"`out` must be a writeable C-contiguous float32 numpy array of shape [{n}, {C}, {H}, {W}]"
+                             f" (got {type(out).__name__} {getattr(out, 'dtype', None)} {getattr(out, 'shape', None)})")
 
     def roundtrip_batch(self, time_stamps, data=None, save_root=None, workers=12, sink=None, out=None,
                         return_format='de_normalized'):
@@ -414,6 +477,7 @@ class cra5_api:
             raise ValueError(f"unknown return_format {return_format!r}")
         denorm = return_format != 'normalized'
         self.net._require_gpu()
+        self._check_out(out, len(time_stamps))
         frames = list(data) if data is not None else [None] * len(time_stamps)
 
         def one(item):
@@ -437,8 +501,7 @@ class cra5_api:
         self.net._require_gpu()
         C = self.net.cfg['out_chans']
         H, W = self.net.cfg['img_size']
-        if out is not None and tuple(out.shape) != (len(paths), C, H, W):
-            raise ValueError("`out` must be a float32 array of shape [n_frames, C, H, W]")
+        self._check_out(out, len(paths))
 
         return self._pipeline(workers).map(lambda it: self._decode_one(it[0], it[1], denorm, out, sink),
                                            list(enumerate(paths)))

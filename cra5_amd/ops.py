@@ -166,8 +166,10 @@ def copy_h2d_staged(dst, src_np, pinned, threads=None):
     """host numpy array (C-contiguous) -> device tensor `dst` of the same byte size, through the pinned tensor
     `pinned`, on the current stream (cra5_copy_h2d_staged): chunked, host memcpy overlapped with the DMA."""
     n = src_np.nbytes
-    assert src_np.flags["C_CONTIGUOUS"] and dst.is_contiguous() and dst.numel() * dst.element_size() == n
-    assert pinned.is_pinned() and pinned.numel() * pinned.element_size() >= n
+    if not (src_np.flags["C_CONTIGUOUS"] and dst.is_cuda and dst.is_contiguous() and dst.numel() * dst.element_size() == n):
+        raise ValueError("copy_h2d_staged: the host array must be C-contiguous and the device tensor contiguous, of the same byte size")
+    if not (pinned.is_pinned() and pinned.numel() * pinned.element_size() >= n):
+        raise ValueError("copy_h2d_staged: `pinned` must be a pinned tensor of at least the frame's byte size")
     check(lib().cra5_copy_h2d_staged(_p(dst), ctypes.c_void_p(src_np.ctypes.data), ctypes.c_void_p(pinned.data_ptr()),
                                      n, COPY_CHUNK, threads or COPY_THREADS, _stream()), "cra5_copy_h2d_staged")
     return dst
@@ -176,8 +178,12 @@ def copy_h2d_staged(dst, src_np, pinned, threads=None):
 def copy_d2h_staged(dst_np, src, pinned, threads=None):
     """device tensor -> host numpy array through `pinned`; returns when `dst_np` holds the data."""
     n = dst_np.nbytes
-    assert dst_np.flags["C_CONTIGUOUS"] and src.is_contiguous() and src.numel() * src.element_size() == n
-    assert pinned.is_pinned() and pinned.numel() * pinned.element_size() >= n
+    if not (dst_np.flags["C_CONTIGUOUS"] and dst_np.flags["WRITEABLE"] and src.is_cuda and src.is_contiguous()
+            and src.numel() * src.element_size() == n):
+        raise ValueError("copy_d2h_staged: the host array must be writeable and C-contiguous, the device tensor contiguous, "
+                         "of the same byte size")
+    if not (pinned.is_pinned() and pinned.numel() * pinned.element_size() >= n):
+        raise ValueError("copy_d2h_staged: `pinned` must be a pinned tensor of at least the frame's byte size")
     check(lib().cra5_copy_d2h_staged(ctypes.c_void_p(dst_np.ctypes.data), _p(src), ctypes.c_void_p(pinned.data_ptr()),
                                      n, COPY_CHUNK, threads or COPY_THREADS, _stream()), "cra5_copy_d2h_staged")
     return dst_np
