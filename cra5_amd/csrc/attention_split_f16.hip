@@ -110,17 +110,29 @@ constexpr int WS_ROW = 68;   // floats per query of a partial: O[64], m, l, 2 pa
 // PLAIN (reduced-precision mode only, round 5): qkv rows, the pad row and the out_s rows are PLAIN f16 - element n at
 // half n of the row (row pitch unchanged: a plain row is the first half of a split row) - as the plain-output qkv GEMM
 // writes them and the plain-operand proj GEMM reads them: K / V tiles are staged as 128-byte instead of 256-byte rows.
-template <int NW, bool HI, bool GLOBAL, bool BAL = false, bool PLAIN = false>
+// PERSIST (round 6): windowed launches as ONE persistent 12-wave work-group per CU that walks a list of UNITS.  A
+// (window, head) pair has T = L / 32 wave-tiles of queries (18 for the model's 576-token windows): T / 12 FULL units
+// (12 wave-tiles x the whole key loop) and, for the T % 12 = 6 tiles that are left, one SPLIT unit - waves 0..5 run the
+// six tiles over the first half of the keys, waves 6..11 the SAME six tiles over the second half (two K / V tiles staged
+// per step, one per wave group), and the two un-normalised partials (m, l, O) are merged through LDS in fixed order
+// before the store.  Every wave of every unit is busy (the 4-wave form's fifth work-group of a pair was half empty), K / V
+// of a pair are staged 1.5 x instead of 5 x, a step runs 3 waves per SIMD behind ONE barrier domain like the whole-grid
+// launch, and the per-launch fixed cost (two rounds of prologue + epilogue under contention: 20 of 105 us) is paid once
+// per unit on a CU that has nothing else to wait for.  Units are dealt so that the work-groups that got one FULL unit
+// more take no SPLIT unit first (576 units on 256 CUs: 36 key steps at most, 30.4 on average).
+template <int NW, bool HI, bool GLOBAL, bool BAL = false, bool PLAIN = false, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void window_attention_split_kernel(
     const unsigned short *__restrict__ qkv, long ldq /* halves per row = 2*Kp */,
     const unsigned short *__restrict__ pad_row, float *__restrict__ out, unsigned short *__restrict__ out_s,
-    int Kp_out, int C, int heads, WinGeom g, int q_tiles, float scale, BalArgs bal) {
+    int Kp_out, int C, int heads, WinGeom g, int q_tiles /* PERSIST: number of windows */, float scale, BalArgs bal) {
   static_assert(!BAL || GLOBAL, "the balanced schedule is for whole-grid launches");
   static_assert(!PLAIN || HI, "plain rows carry no lo plane");
+  static_assert(!PERSIST || (!GLOBAL && !BAL && NW % 2 == 0), "the persistent unit walk is for windowed launches");
   constexpr int NT = NW * 64;
   constexpr int PPR = PLAIN ? 8 : 16;             // 16-byte pieces per K (or V) row of one head: 64 d x (hi | hi + lo)
   constexpr int PIECES = 32 * PPR;                // 16-byte pieces per K (or V) tile
-  constexpr int STG = (PIECES + NT - 1) / NT;
+  constexpr int NGRP = PERSIST ? 2 : 1;           // wave groups with a K / V tile of their own (SPLIT units)
+  constexpr int STG = (NGRP * PIECES + NT - 1) / NT;
 
   // [K hi][K lo] : 32 x KS ;  [V hi][V lo] : 32 x VS (row-major like K, transposed by the READ)
   constexpr int KPL = 32 * KS + 32;   // K plane stride (halves): +64 B so hi/lo planes hit different bank halves
@@ -128,9 +140,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // two K buffers and two V^T buffers: tile j+1's scores are issued to the matrix pipe BEFORE
   // the softmax of tile j, so K runs one tile ahead of V; one barrier per key tile.
   constexpr int KBUF = 2 * KPL, VBUF = 2 * VPL;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * KBUF + 2 * VBUF];
-  unsigned short *Ks = lds;
-  unsigned short *Vt = lds + 2 * KBUF;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[NGRP * (2 * KBUF + 2 * VBUF)];
+  unsigned short *Ks = lds;                       // group gq's two K buffers at Ks + gq * 2 * KBUF
+  unsigned short *Vt = lds + NGRP * 2 * KBUF;     // ...            V buffers at Vt + gq * 2 * VBUF
   // windowed launches: byte offset (from qkv) of every window token's row, pad tokens -> the pad
   // row; built once per block so that the per-tile staging needs no division / multiply.
   constexpr int TAB = GLOBAL ? 1 : MAX_WIN_TOKENS;
@@ -177,23 +189,26 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
         s = e;
       }
     }
-  } else {
+  } else if (!PERSIST) {
     const int pid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = pid % q_tiles;
     const int wh_id = pid / q_tiles;
     head = wh_id % heads;
     win = wh_id / heads;
     seg_tile0[0] = qt * NW;
+  } else {
+    head = 0;
+    win = 0;
   }
-  const int wr = win / g.nwc, wc = win - wr * g.nwc;
+  int wr = win / g.nwc, wc = win - wr * g.nwc;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int hoff = head * HD;
+  int hoff = head * HD;
   // halves offset of this head's q / k / v slice inside a split row (64 d = 2 chunks = 128 halves)
-  const long qoff = (PLAIN ? 1L : 2L) * hoff, koff = (PLAIN ? 1L : 2L) * (C + hoff), voff = (PLAIN ? 1L : 2L) * (2 * C + hoff);
+  long qoff = (PLAIN ? 1L : 2L) * hoff, koff = (PLAIN ? 1L : 2L) * (C + hoff), voff = (PLAIN ? 1L : 2L) * (2 * C + hoff);
 
-  if (!GLOBAL) {
+  if (!GLOBAL && !PERSIST) {
     const long long pad_delta = reinterpret_cast<const char *>(pad_row) - reinterpret_cast<const char *>(qkv);
     for (int t = tid; t < L; t += NT) {
       const int tok = token_of(g, wr, wc, t);
@@ -202,11 +217,62 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   }
   constexpr bool IDLE_SKIP = !GLOBAL || BAL;
   bool tab_ready = GLOBAL;
+  // PERSIST: the unit walk of this work-group.  T wave-tiles per (window, head) pair = fg FULL units + (rem ? 1 : 0) unit
+  // of the rem tiles left (SPLIT when rem = NW / 2).  FULL units are dealt round-robin; the r = nF % G work-groups that got
+  // one more of them take no remainder unit before the other G - r have one each.
+  const int pu_T = L / 32, pu_fg = pu_T / NW, pu_rem = pu_T - pu_fg * NW;
+  const int pu_pairs = PERSIST ? q_tiles * heads : 0;
+  const int pu_nF = pu_pairs * pu_fg, pu_nH = pu_rem ? pu_pairs : 0;
+  const int pu_G = (int)gridDim.x, pu_r = pu_nF % pu_G;
+  const int pu_light = (pu_r && pu_G - pu_r > 0) ? pu_G - pu_r : pu_G;      // work-groups the remainder units rotate over
+  int pu_f = (int)blockIdx.x;                                                // next FULL unit of this work-group
+  int pu_h = (pu_light == pu_G) ? (int)blockIdx.x : ((int)blockIdx.x >= pu_r ? (int)blockIdx.x - pu_r : pu_nH);
 #pragma unroll 1
-  for (int seg = 0; seg < n_seg; ++seg) {
-  const int tile0 = seg_tile0[seg], n_active = seg_nact[seg], j0 = seg_j0[seg], j1 = seg_j1[seg];
-  const int tq = (tile0 + wave) * 32 + l31;
-  const int q_tok = (tq < L && wave < n_active) ? token_of(g, wr, wc, tq) : -1;
+  for (int seg = 0; PERSIST || seg < n_seg; ++seg) {
+  int tile0 = seg_tile0[PERSIST ? 0 : seg], n_active = seg_nact[PERSIST ? 0 : seg], j0 = seg_j0[PERSIST ? 0 : seg], j1 = seg_j1[PERSIST ? 0 : seg];
+  bool split = false;         // PERSIST: this unit runs its tiles twice, each wave group over half of the keys
+  if (PERSIST) {
+    int pair;
+    if (pu_f < pu_nF) {
+      pair = pu_f / pu_fg;
+      tile0 = (pu_f - pair * pu_fg) * NW;
+      n_active = NW;
+      pu_f += pu_G;
+    } else if (pu_h < pu_nH) {
+      pair = pu_h;
+      tile0 = pu_fg * NW;
+      split = (2 * pu_rem == NW) && (pu_T % 2 == 0);
+      n_active = pu_rem;
+      pu_h += pu_light;
+    } else {
+      break;
+    }
+#ifdef CRA5_PROBE_SAMEPAIR
+    pair &= 7;      // timing probe only (wrong results): every unit reads the K / V of one of 8 pairs - L2-resident
+#endif
+    head = pair % heads;
+    win = pair / heads;
+    wr = win / g.nwc;
+    wc = win - wr * g.nwc;
+    hoff = head * HD;
+    qoff = (PLAIN ? 1L : 2L) * hoff;
+    koff = (PLAIN ? 1L : 2L) * (C + hoff);
+    voff = (PLAIN ? 1L : 2L) * (2 * C + hoff);
+    j0 = 0;
+    j1 = split ? pu_T / 2 : pu_T;
+    // the row-offset table of this unit's window (every wave is past the last barrier of the previous unit's key loop,
+    // after which nobody reads the table; the barrier below publishes it)
+    const long long pad_delta = reinterpret_cast<const char *>(pad_row) - reinterpret_cast<const char *>(qkv);
+    for (int t = tid; t < L; t += NT) {
+      const int tok = token_of(g, wr, wc, t);
+      tab[t] = (tok >= 0) ? (long long)tok * ldq * 2 : pad_delta;
+    }
+  }
+  // SPLIT unit: wave group gw = wave / (NW / 2) runs tiles tile0 + wave % (NW / 2) over key tiles [gw * n_tiles, + n_tiles)
+  const int gw = (PERSIST && split) ? wave / (NW / 2) : 0;
+  const int wq = (PERSIST && split) ? wave - gw * (NW / 2) : wave;
+  const int tq = (tile0 + wq) * 32 + l31;
+  const int q_tok = (tq < L && wq < n_active) ? token_of(g, wr, wc, tq) : -1;
   const bool wave_active = __any(q_tok >= 0);
   // (also publishes the row-offset table of a windowed launch; between two segments every wave is past the last
   // barrier of the previous key loop, after which nobody reads the K / V buffers any more)
@@ -261,7 +327,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   constexpr bool TWO = STG == 2;
   // thread -> (row, piece) of its two K pieces and (row, two pieces) of V; indexes past the tile
   // (NW = 6: 384 threads x 2 > 512 pieces) are clamped: loaded redundantly, never stored.
-  const int krow0 = min(tid / PPR, 31), krow1 = min((tid + NT) / PPR, 31);
+  // PERSIST: rows 32..63 of the piece index are wave group 1's tile (SPLIT units only; n_pieces = PIECES otherwise)
+  const int n_pieces = (PERSIST && split) ? 2 * PIECES : PIECES;
+  const int krow0 = PERSIST ? ((tid / PPR) & 31) : min(tid / PPR, 31), krow1 = PERSIST ? (((tid + NT) / PPR) & 31) : min((tid + NT) / PPR, 31);
+  const int kgrp0 = PERSIST ? ((tid / PPR) >> 5) & 1 : 0, kgrp1 = PERSIST ? (((tid + NT) / PPR) >> 5) & 1 : 0;
+  const int ktile0 = kgrp0 * (j1 - j0), ktile1 = kgrp1 * (j1 - j0);       // first key tile of the piece's wave group
   const long kcol = koff + (tid % PPR) * 8;                                 // halves
   const long vcol = voff + (tid % PPR) * 8;
   // whole-grid launches walk three running row pointers (+32 rows per tile); windowed ones look
@@ -275,8 +345,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(qkv) + tab[(JJ)*32 + (ROW)])
   // (waves whose pieces fall past the 512 of a tile - 4 of 12, or the second piece of 4 of 6 - skip the
   // loads and their address arithmetic altogether: the conditions are wave-uniform)
-  const bool stage0 = (NT <= PIECES) || (tid < PIECES);
-  const bool stage1 = TWO && (tid + NT < PIECES);
+  const bool stage0 = PERSIST ? (tid < n_pieces) : ((NT <= PIECES) || (tid < PIECES));
+  const bool stage1 = TWO && (tid + NT < (PERSIST ? n_pieces : PIECES));
 #define CRA5_K_LOAD(J)                                                                    \
   if (stage0) {                                                                           \
     if (GLOBAL) {                                                                         \
@@ -287,8 +357,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       kq1 += st_;                                                                         \
     } else {                                                                              \
       const int jj_ = min((J), n_tiles - 1);                                              \
-      sk0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + kcol);                \
-      if (stage1) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + kcol);    \
+      sk0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile0, krow0) + kcol);       \
+      if (stage1) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile1, krow1) + kcol); \
     }                                                                                     \
   }
 #define CRA5_V_LOAD(J)                                                                    \
@@ -301,28 +371,30 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       vq1 += st_;                                                                         \
     } else {                                                                              \
       const int jj_ = min((J), n_tiles - 1);                                              \
-      sv0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + vcol);                \
-      if (stage1) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + vcol);    \
+      sv0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile0, krow0) + vcol);       \
+      if (stage1) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile1, krow1) + vcol); \
     }                                                                                     \
   }
   // piece -> (chunk = piece>>3, plane = (piece>>2)&1, d0 = 32*chunk + 8*(piece&3))
 #define CRA5_K_STORE1(P, BUF)                                                             \
   {                                                                                       \
     const int idx = tid + (P)*NT;                                                         \
-    if (idx < PIECES) {                                                                   \
-      const int row = idx / PPR, piece = idx % PPR;                                       \
+    if (idx < n_pieces) {                                                                 \
+      const int row_ = idx / PPR, piece = idx % PPR;                                      \
+      const int row = PERSIST ? (row_ & 31) : row_, gq_ = PERSIST ? (row_ >> 5) : 0;      \
       const int plane = PLAIN ? 0 : (piece >> 2) & 1, d0 = PLAIN ? 8 * piece : 32 * (piece >> 3) + 8 * (piece & 3); \
-      *reinterpret_cast<uint4 *>(Ks + (BUF)*KBUF + plane * KPL + row * KS + d0) = sk##P;  \
+      *reinterpret_cast<uint4 *>(Ks + gq_ * 2 * KBUF + (BUF)*KBUF + plane * KPL + row * KS + d0) = sk##P;  \
     }                                                                                     \
   }
 #define CRA5_K_STORE(BUF) { CRA5_K_STORE1(0, BUF) if (TWO) CRA5_K_STORE1(1, BUF) }
 #define CRA5_V_STORE1(P, BUF)                                                             \
   {                                                                                       \
     const int idx = tid + (P)*NT;                                                         \
-    if (idx < PIECES) {                                                                   \
-      const int row = idx / PPR, piece = idx % PPR;                                       \
+    if (idx < n_pieces) {                                                                 \
+      const int row_ = idx / PPR, piece = idx % PPR;                                      \
+      const int row = PERSIST ? (row_ & 31) : row_, gq_ = PERSIST ? (row_ >> 5) : 0;      \
       const int plane = PLAIN ? 0 : (piece >> 2) & 1, d0 = PLAIN ? 8 * piece : 32 * (piece >> 3) + 8 * (piece & 3); \
-      *reinterpret_cast<uint4 *>(Vt + (BUF)*VBUF + plane * VPL + row * VS + d0) = sv##P;  \
+      *reinterpret_cast<uint4 *>(Vt + gq_ * 2 * VBUF + (BUF)*VBUF + plane * VPL + row * VS + d0) = sv##P;  \
     }                                                                                     \
   }
 #define CRA5_V_STORE(BUF) { CRA5_V_STORE1(0, BUF) if (TWO) CRA5_V_STORE1(1, BUF) }
@@ -357,14 +429,14 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
 #define CRA5_MFMA_FROM(D, A, B, C) (D) = (C)
 #endif
 
-  const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
+  const unsigned short *k_base = Ks + gw * 2 * KBUF + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
   // V^T fragments (A operand: row d = l31, 8 keys per lane) come out of the ROW-MAJOR V image through
   // ds_read_b64_tr_b16: inside each 16-lane group, lane l' receives element (l' & 3) of the 8-byte
   // slots addressed by lanes (l' >> 2) + {0, 4, 8, 12} (probed: tools/probes/tr_probe.hip).  Lane l'
   // therefore ADDRESSES V[kbase + (l' >> 2)][d0 + 4 (l' & 3) ..+3] and RECEIVES V[kbase + 0..3][d0 + l'],
   // d0 = 16 ((lane >> 4) & 1): four consecutive keys of its own d.  Row stride 192 B puts the four
   // key rows x two d-halves of a 32-lane LDS cycle on 8 disjoint 8-bank ranges (conflict-free).
-  const unsigned short *v_base = Vt + (4 * h + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const unsigned short *v_base = Vt + gw * 2 * VBUF + (4 * h + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   // + buf*VBUF + plane*VPL + (16*t + 8*a)*VS + 32*dt
 
   // cross-half max: lanes l and l+32 own the two halves of one query's 32 scores
@@ -618,8 +690,42 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   }
   if (jt < n_loop) key_tile(jt, s_cur, s_alt);
 
+  if (PERSIST && split) {
+    // merge of the two key halves of a SPLIT unit: wave group 1 parks (m, l) and its 32 accumulator registers in the K / V
+    // area (after the key loop's last barrier nobody reads it), 16 registers per round; group 0 combines them with its
+    // own - first key half first, fixed association - and stores.  [wq][register][lane] floats: conflict-free.
+    float *scr = reinterpret_cast<float *>(lds);
+    float ma = 1.f, mb = 1.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (gw == 1) {
+        float *dst = scr + (size_t)wq * 18 * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r * 64] = o[t][r];
+        if (t == 0) {
+          dst[16 * 64] = m_run;
+          dst[17 * 64] = l_run;
+        }
+      }
+      __syncthreads();
+      if (gw == 0) {
+        const float *src = scr + (size_t)wq * 18 * 64 + lane;
+        if (t == 0) {
+          const float m_b = src[16 * 64], l_b = src[17 * 64];
+          const float M = fmaxf(m_run, m_b);
+          ma = __builtin_amdgcn_exp2f(m_run - M);
+          mb = __builtin_amdgcn_exp2f(m_b - M);
+          l_run = fmaf(l_b, mb, l_run * ma);
+          m_run = M;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = fmaf(src[r * 64], mb, o[t][r] * ma);
+      }
+      __syncthreads();
+    }
+  }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (BAL && seg_part[seg] >= 0) {
+  if (BAL && seg_part[PERSIST ? 0 : seg] >= 0) {
     // un-normalised partial of this key range: O, running max (log2 domain), sum - merged by attention_merge_kernel
     if (q_tok >= 0) {
       float *wrow = bal.ws + (((((size_t)head * bal.n_grp + seg_grp[seg]) * bal.maxp + seg_part[seg]) * NW + wave) * 32 + l31) * WS_ROW;
@@ -643,7 +749,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // v_permlane32_swap per dword turns the groups (g, g + 1) of the two half-waves into 16 contiguous bytes per lane:
   // lanes 0-31 get columns 16 p .. 16 p + 7 of the pair, lanes 32-63 the next eight (8 sixteen-byte stores per lane).
   {
-    const bool live = q_tok >= 0;
+    const bool live = q_tok >= 0 && gw == 0;        // (SPLIT units: wave group 0 holds the merged result)
     const float inv = live ? 1.0f / l_tot : 0.0f;   // (dead lanes take part in the swaps below: keep their values finite)
     float *orow = (out && live) ? out + (size_t)q_tok * C + hoff : nullptr;
     unsigned short *srow = (out_s && live) ? out_s + (size_t)q_tok * 2 * Kp_out : nullptr;
@@ -830,6 +936,38 @@ int launch(const unsigned short *qkv, long ldq, const unsigned short *pad_row, f
   return (int)hipGetLastError();
 }
 
+// Windowed launch as persistent 12-wave work-groups walking (window, head) units (PERSIST above): one work-group per CU.
+template <bool HI, bool PLAIN = false>
+int launch_persist(const unsigned short *qkv, long ldq, const unsigned short *pad_row, float *out, unsigned short *out_s,
+                   int Kp_out, int C, int heads, int H, int W, int wh, int ww, float scale, hipStream_t st) {
+  WinGeom g;
+  g.H = H;
+  g.W = W;
+  g.wh = wh;
+  g.ww = ww;
+  const int nwr = (H + wh - 1) / wh;
+  g.nwc = (W + ww - 1) / ww;
+  const int T = (wh * ww) / 32, pairs = nwr * g.nwc * heads;
+  const int units = pairs * (T / NW_GLOBAL + (T % NW_GLOBAL ? 1 : 0));
+  const int grid = units < cu_count() ? units : cu_count();
+  hipLaunchKernelGGL((window_attention_split_kernel<NW_GLOBAL, HI, false, false, PLAIN, true>), dim3(grid), dim3(NW_GLOBAL * 64),
+                     0, st, qkv, ldq, pad_row, out, out_s, Kp_out, C, heads, g, nwr * g.nwc, scale, BalArgs{});
+  return (int)hipGetLastError();
+}
+
+// Windowed launches: the 4-wave work-groups of rounds 2-5 (three per CU) stay the product path.  The persistent 12-wave
+// unit walk (round 6) is built, tested and SLOWER - 117 vs 92 us on the model's 24 x 24 windows (profiles/r06_attn_window_ab.txt):
+// with one work-group per CU nothing runs under a unit's prologue / epilogue (three independent 4-wave work-groups
+// stagger themselves), and a 12-wave barrier domain steps in 2.8 us where the three small ones average 2.2.
+// CRA5_ATTN_WINDOWS=persistent selects it (A / B measurements, tools/attn_window_ab.py).
+bool windows_persistent() {
+  static const bool v = [] {
+    const char *e = getenv("CRA5_ATTN_WINDOWS");
+    return e && e[0] == 'p';
+  }();
+  return v;
+}
+
 }  // namespace
 
 static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split, float *out,
@@ -873,6 +1011,12 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   // window, K / V staged three times instead of five) looks better on paper and ran with ONE work-group per CU: its
   // waves land on the SIMDs 2-2-1-1, a second work-group would put four 156-register waves on one SIMD (3 fit), so
   // 864 work-groups took 3.4 rounds instead of 1.7.  Four waves are one per SIMD: three work-groups always fit.
+  // (opt-in, round 6: windows of >= 12 wave-tiles as persistent 12-wave units - see windows_persistent())
+  if (L / 32 >= NW_GLOBAL && windows_persistent()) {
+    if (plain) return launch_persist<true, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+    if (hi_only) return launch_persist<true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+    return launch_persist<false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
+  }
   if (plain) return launch<4, true, false, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
   if (hi_only) CRA5_ATT_GO(4, true, false);
   CRA5_ATT_GO(4, false, false);
