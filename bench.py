@@ -553,12 +553,14 @@ def rocprof_gemm_frac(f16=False):
 
 
 def main():
+    from cra5_amd.config import RuntimeConfig
+    rc0 = RuntimeConfig.from_env()               # the ONE place CRA5_* settings are read; flags below override its fields
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--quality", type=int, default=268)
-    ap.add_argument("--precision", choices=("fp32", "f16"), default=os.environ.get("CRA5_PRECISION", "fp32"),
+    ap.add_argument("--precision", choices=("fp32", "f16"), default=rc0.precision,
                     help="fp32 (default, the headline: fp32-accurate split MFMA) | f16: BASELINE.json configs[4], "
                          "reduced-precision g_a/g_s (plain f16 operands), RMSE-gated - NOT the headline metric")
     ap.add_argument("--settle-batches", type=int, default=40,
@@ -578,7 +580,7 @@ def main():
     ap.add_argument("--exclusive", action="store_true",
                     help="timed region with exclusive GPU phases (one frame's kernels at a time) instead of "
                          "overlapping HIP streams")
-    ap.add_argument("--gpu-slots", type=int, default=int(os.environ.get("CRA5_GPU_SLOTS", "3")),
+    ap.add_argument("--gpu-slots", type=int, default=rc0.gpu_slots,
                     help="at most this many frames inside a GPU phase at a time (0 = unlimited)")
     ap.add_argument("--roofline-steps", type=int, default=2,
                     help="frames of the un-overlapped kernel-timing pass run after the timed region")
@@ -600,11 +602,11 @@ def main():
     ap.add_argument("--no-clock-sampler", action="store_true", help="no shader-clock sampler wave beside the timed region")
     ap.add_argument("--no-numa-bind", action="store_true",
                     help="do not pin a rank's threads to its GPU's NUMA node share of the host cores")
-    ap.add_argument("--numa-bind-single", choices=("on", "off"), default=os.environ.get("CRA5_NUMA_BIND_SINGLE", "on"),
+    ap.add_argument("--numa-bind-single", choices=("on", "off"), default="on" if rc0.numa_bind_single else "off",
                     help="N = 1: bind the process to the GPU's NUMA node as the N > 1 ranks are (frame threads, rANS work and "
                          "the pageable -> pinned copies of the API samples then run beside the GPU's root complex); the CPU "
                          "baseline leg lifts the bind again")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("CRA5_INFLIGHT", "12")),
+    ap.add_argument("--inflight", type=int, default=rc0.inflight,
                     help="frames in flight per GPU (host rANS of one frame overlaps GPU work of the others)")
     args = ap.parse_args()
 
@@ -617,6 +619,7 @@ def main():
 
     from cra5_amd import dist as D
     from cra5_amd import ops, synth
+    from cra5_amd._lib import LIB_PATH
     from cra5_amd.zoo import vaeformer_pretrained
 
     cpu_threads = args.cpu_threads or host_cpu_info()[1]
@@ -661,7 +664,9 @@ def main():
         args.inflight = pre["inflight"]
     STAGE[0] = "model build"
 
-    net = vaeformer_pretrained(quality=args.quality, pretrained=False)
+    rc = rc0.replace(precision=args.precision, gpu_slots=args.gpu_slots, inflight=args.inflight,
+                     gpu_exclusive=bool(args.exclusive), numa_bind_single=args.numa_bind_single == "on")
+    net = vaeformer_pretrained(quality=args.quality, pretrained=False, runtime=rc)
     synth.load_synthetic(net, seed=7)
     net = net.to(dev)
     C = args.quality
@@ -833,6 +838,8 @@ def main():
                    "parallelism": f"frame-sharded x{world}, weights replicated",
                    "distinct_frames_per_rank": pool, "frame_seeds_rank0": [seed_of_step[0], seed_of_step[-1]],
                    "frames_in_flight_per_gpu": args.inflight, "preflight": pre,
+                   # the run's settings as ONE object (cra5_amd/config.py: defaults < CRA5_* environment < bench.py flags)
+                   "runtime": dict(rc.replace(inflight=args.inflight).describe(), native_library=os.path.basename(LIB_PATH)),
                    "host": {"frame_threads_total": args.inflight * world, "host_threads": os.cpu_count(),
                             "numa_bind_rank0": numa, "self_launched": os.environ.get("CRA5_SELF_LAUNCHED") == "1",
                             # N > 1: every rank's CPU mask after the bind, and how many of its threads (frame threads,
@@ -1057,7 +1064,7 @@ def main():
                         "test_full268_reduced_precision_mode asserts it against the reference golden)",
                 "what": "same pipeline and frames as the timed region with CRA5_PRECISION=f16 (1 MFMA per product in g_a / "
                         "g_s GEMMs and attention; h_a / h_s / entropy side unchanged so both sides derive the same CDF "
-                        f"indexes); g_a / g_s activations and weights as PLAIN f16 rows (CRA5_F16_LAYOUT={net.f16_layout}); "
+                        f"indexes); g_a / g_s activations and weights as PLAIN f16 rows (VAEformer.f16_layout = {net.f16_layout!r}); "
                         f"{n16}-frame region after two warm batches, outside the timed region",
                 "frac_of_f16_roofline": FLOP_PER_FRAME * n16 / t16 / (PEAK_F16_MFMA_TFLOPS * 1e12)}
         except Exception as ex:  # noqa: BLE001

@@ -35,7 +35,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class cra5_api:
-    def __init__(self, config=None, local_root=None, device=None, ceph_cfg=None, weights=None, quality=268):
+    def __init__(self, config=None, local_root=None, device=None, ceph_cfg=None, weights=None, quality=268, runtime=None):
         self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
         print(f'The serving device is {self.device}')
         with open(os.path.join(_HERE, "data", "era5_stats.json")) as f:
@@ -57,14 +57,16 @@ class cra5_api:
         self.channels_to_vname, self.vname_to_channels = self.channel_vname_mapping()
         self.local_root = local_root or f'{os.getcwd()}/data'
         # batch methods: host threads per frame copy between pageable and pinned memory (1 = one numpy copy on the frame thread)
-        self.batch_copy_threads = int(os.environ.get("CRA5_BATCH_COPY_THREADS", "1"))
+        from .config import RuntimeConfig
+        self.runtime = runtime if runtime is not None else (getattr(weights, "runtime", None) or RuntimeConfig.from_env())
+        self.batch_copy_threads = self.runtime.batch_copy_threads
         # batch methods: ONE frame per direction on the host link at a time (round 6).  Twelve frame threads that all
         # issue their 1.11 GB H2D at once share the link - every frame lands after 12 transfer times, the GPU idles
         # until then and the frames then queue for it in a convoy; one at a time, the first frame lands after one
         # transfer time and the GPU starts while the next frame is on the wire.  The link itself runs 57 GB/s in either
         # direction and 97 GB/s both ways at once (profiles/r06_link_probe.txt), so H2D and D2H get a gate each.
         import threading
-        self.link_serial = True
+        self.link_serial = self.runtime.link_serial
         self._link_gate = {"h2d": threading.Lock(), "d2h": threading.Lock()}
         self.phase_log = None       # a list: (frame tag, phase, t_start, t_end) per batch-path phase (tools/api_phase_probe.py)
         self._era5 = None
@@ -144,7 +146,7 @@ class cra5_api:
         arr = np.ascontiguousarray(data, dtype=np.float32)
         pin = self.net._pinned("api_x_in", tuple(arr.shape), torch.float32)
         xdev = self.net._buf("api_x_dev", tuple(arr.shape))
-        return ops.copy_h2d_staged(xdev, arr, pin)
+        return ops.copy_h2d_staged(xdev, arr, pin, threads=self.runtime.copy_threads)
 
     def _finite_probe(self, frame):
         """One reduction pass over the frame (ops.probe_sums), asynchronous: NaN / inf anywhere make a partial sum
@@ -551,6 +553,6 @@ class cra5_api:
                 if out.dtype != np.float32 or tuple(out.shape) != tuple(src.shape) or not out.flags["C_CONTIGUOUS"]:
                     raise ValueError("`out` must be a C-contiguous float32 array of shape %r" % (tuple(src.shape),))
                 pin = self.net._pinned("api_x_out", tuple(src.shape), torch.float32)
-                x_hat = ops.copy_d2h_staged(out, src, pin)
+                x_hat = ops.copy_d2h_staged(out, src, pin, threads=self.runtime.copy_threads)
         torch.cuda.synchronize()
         return dict(x_hat=x_hat, decoding_time=time.time() - decoding_start)

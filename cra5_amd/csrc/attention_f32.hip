@@ -298,10 +298,15 @@ extern "C" int cra5_window_attention_f32(const float *qkv, const float *pad_row,
     // but every block still walks all 21 key tiles, each a serial chain of exact-f32 MFMAs:
     // measured 83 / 88 / 102 us for 4 / 2 / 1 waves (tools/attn_bench.py) - the fix is splitting
     // the KEYS over waves, not the queries.  CRA5_ATT72_NW overrides (1 | 2 | 4).
+// variant builds only (tools/build_variant.sh): the product library reads no environment variable
+#ifdef CRA5_TUNING_ENV
     static const int forced = [] {
       const char *e = getenv("CRA5_ATT72_NW");
       return e ? atoi(e) : 0;
     }();
+#else
+    constexpr int forced = 0;
+#endif
     const int nwr = (H + wh - 1) / wh, nwc = (W + ww - 1) / ww;
     const long blocks4 = (long)((L + 127) / 128) * nwr * nwc * heads;
     (void)blocks4;

@@ -247,9 +247,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     } else {
       break;
     }
-#ifdef CRA5_PROBE_SAMEPAIR
-    pair &= 7;      // timing probe only (wrong results): every unit reads the K / V of one of 8 pairs - L2-resident
-#endif
     head = pair % heads;
     win = pair / heads;
     wr = win / g.nwc;
@@ -955,19 +952,6 @@ int launch_persist(const unsigned short *qkv, long ldq, const unsigned short *pa
   return (int)hipGetLastError();
 }
 
-// Windowed launches: the 4-wave work-groups of rounds 2-5 (three per CU) stay the product path.  The persistent 12-wave
-// unit walk (round 6) is built, tested and SLOWER - 117 vs 92 us on the model's 24 x 24 windows (profiles/r06_attn_window_ab.txt):
-// with one work-group per CU nothing runs under a unit's prologue / epilogue (three independent 4-wave work-groups
-// stagger themselves), and a 12-wave barrier domain steps in 2.8 us where the three small ones average 2.2.
-// CRA5_ATTN_WINDOWS=persistent selects it (A / B measurements, tools/attn_window_ab.py).
-bool windows_persistent() {
-  static const bool v = [] {
-    const char *e = getenv("CRA5_ATTN_WINDOWS");
-    return e && e[0] == 'p';
-  }();
-  return v;
-}
-
 }  // namespace
 
 static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split, float *out,
@@ -982,7 +966,13 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   hipStream_t st = (hipStream_t)stream;
   const int L = wh * ww;
   // hi_only: 0 = fp32-accurate, 1 = reduced precision on split rows, 3 = reduced precision on PLAIN f16 rows (qkv, the
-  // pad row and out_split: element n at half n; row pitches unchanged)
+  // pad row and out_split: element n at half n; row pitches unchanged); + CRA5_ATTN_PERSISTENT_UNITS (4): windowed
+  // launches as persistent 12-wave units.  The 4-wave work-groups of rounds 2-5 (three per CU) stay the default: the unit
+  // walk is built, tested and SLOWER - 117 vs 92 us on the model's 24 x 24 windows (profiles/r06_attn_window_ab.txt): with
+  // one work-group per CU nothing runs under a unit's prologue / epilogue (three independent 4-wave work-groups stagger
+  // themselves), and a 12-wave barrier domain steps in 2.8 us where the three small ones average 2.2.
+  const bool persistent_units = (hi_only & CRA5_ATTN_PERSISTENT_UNITS) != 0;
+  hi_only &= ~CRA5_ATTN_PERSISTENT_UNITS;
   if (hi_only != 0 && hi_only != 1 && hi_only != 3) return CRA5_ERR_ARG;
   const bool plain = hi_only == 3;
   const long ldq = 2L * qkv_kp;
@@ -1012,7 +1002,7 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   // waves land on the SIMDs 2-2-1-1, a second work-group would put four 156-register waves on one SIMD (3 fit), so
   // 864 work-groups took 3.4 rounds instead of 1.7.  Four waves are one per SIMD: three work-groups always fit.
   // (opt-in, round 6: windows of >= 12 wave-tiles as persistent 12-wave units - see windows_persistent())
-  if (L / 32 >= NW_GLOBAL && windows_persistent()) {
+  if (L / 32 >= NW_GLOBAL && persistent_units) {
     if (plain) return launch_persist<true, true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
     if (hi_only) return launch_persist<true>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);
     return launch_persist<false>(qkv_split, ldq, pad_row_split, out, out_split, out_kp, C, heads, H, W, wh, ww, scale, st);

@@ -567,10 +567,15 @@ static int gemm_dispatch(const unsigned short *A, long lda, const unsigned short
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
 #define CRA5_GO(WM, WN, TM, TN, LK) \
   return launch<WM, WN, TM, TN, LK>(A, lda, W, ldw, C, ldc, C_split, ldcs, bias, res, ldr, M, N, Kp, wscale_inv, flags, st)
+// variant builds only: the product library reads no environment variable
+#if defined(CRA5_TUNING_ENV) || defined(CRA5_GEMM_TRACE)
   static const int forced = [] {
     const char *e = getenv("CRA5_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
+#else
+  constexpr int forced = 0;
+#endif
   const bool longk = Kp > 8192;
   // plain-f16 operands / output exist in the wide reduced-precision form only (the caller falls back to split rows)
   constexpr int PLAIN_ANY = CRA5_GEMM_A_PLAIN | CRA5_GEMM_W_PLAIN | CRA5_GEMM_OUT_PLAIN;

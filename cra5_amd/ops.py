@@ -159,7 +159,7 @@ class KernelTimer:
 TIMER = None  # set to a KernelTimer by bench.py
 
 COPY_CHUNK = 32 << 20
-COPY_THREADS = int(os.environ.get("CRA5_COPY_THREADS", "8"))
+COPY_THREADS = 8     # host threads of one staged copy; cra5_api / VAEformer pass RuntimeConfig.copy_threads explicitly
 
 
 def copy_h2d_staged(dst, src_np, pinned, threads=None):
@@ -485,7 +485,7 @@ def attention_balanced_plan(n_tokens, heads):
 
 
 def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_split=None, hi_only=False, workspace=None,
-                           balanced=None):
+                           balanced=None, persistent_units=False):
     """qkv_s: SplitMat [H*W, 3C]; pad_s: SplitMat [1, 3C] (the split qkv bias).  workspace: a device byte tensor
     of >= attention_workspace_bytes(H*W, heads) -> the balanced schedule for whole-grid launches (balanced=True with
     workspace=None: a plan that needs no workspace)."""
@@ -506,6 +506,8 @@ def window_attention_split(qkv_s, pad_s, heads, H, W, wh, ww, out=None, out_spli
         assert not pad_s.plain
     if out_split is not None:
         out_split.plain = hi_flag == 3
+    if persistent_units:
+        hi_flag |= 4          # CRA5_ATTN_PERSISTENT_UNITS: the alternative windowed schedule (measurements, tests)
     ev = TIMER.start() if TIMER is not None else None
     if workspace is not None or balanced:
         assert workspace is None or (workspace.is_cuda and workspace.is_contiguous())

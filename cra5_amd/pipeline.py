@@ -24,7 +24,7 @@ class FramePipeline:
         # A frame thread coming back from a GIL-free entropy-coder call must re-take the GIL from the
         # threads that are busy launching kernels; CPython hands it over only every switch interval
         # (5 ms by default - measured: +20 ms on each 13-18 ms host phase with 8 frames in flight).
-        si = float(os.environ.get("CRA5_SWITCH_INTERVAL", "0.0002"))
+        si = float(getattr(getattr(net, "runtime", None), "switch_interval_s", 0.0002))
         if si > 0 and sys.getswitchinterval() > si:
             sys.setswitchinterval(si)
         self._tls = threading.local()

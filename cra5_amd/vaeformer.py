@@ -30,6 +30,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import ERR_RANGE, Cra5Error, StreamDesyncError
+from .config import RuntimeConfig
 from .entropy import EntropyBottleneck, GaussianConditional, get_scale_table
 
 __all__ = ["VAEformer", "config_for", "block_windows"]
@@ -292,18 +293,21 @@ class VAEformer(nn.Module):
         self.gaussian_conditional = GaussianConditional(None)
         # GPU phases of concurrent frames: exclusive (one frame's kernels at a time) or shared
         # (streams overlap: other frames' blocks fill the tail / epilogue gaps of a kernel)
-        self.gpu_exclusive = os.environ.get("CRA5_GPU_EXCLUSIVE", "1") != "0"
-        self._attn_mode = os.environ.get("CRA5_ATTN", "split")   # "split" (f16-MFMA, fp32-accurate) | "f32"
-        # whole-grid attention: balanced 12 + 8-wave passes + key-split leftover (csrc/attention_split_f16.hip, BAL);
-        # CRA5_ATTN_BALANCED=0 keeps the plain 27-work-groups-per-head launch (A/B runs)
-        self.attn_balanced = os.environ.get("CRA5_ATTN_BALANCED", "1") != "0"
-        self._gemm_mode = os.environ.get("CRA5_GEMM", "split")
-        if self._gemm_mode not in ("split", "f32"):
-            raise ValueError("CRA5_GEMM must be 'split' or 'f32'")
+        # Runtime settings: ONE RuntimeConfig object (cra5_amd/config.py), from the caller (`runtime=`) or from the
+        # environment - the only place of the package that reads CRA5_* settings.  The attributes below are its fields,
+        # kept as plain attributes so that a caller / bench.py can change them between frames.
+        rc = kwargs.pop("runtime", None)
+        self.runtime = rc = rc if rc is not None else RuntimeConfig.from_env()
+        self.gpu_exclusive = rc.gpu_exclusive
+        self._attn_mode = rc.attn_engine   # "split" (f16-MFMA, fp32-accurate) | "f32"
+        # whole-grid attention: balanced 12-wave passes + key-split leftover (csrc/attention_split_f16.hip, BAL); False keeps
+        # the plain 27-work-groups-per-head launch (a bit-identical-on-full-tiles alternative: tests flip the attribute)
+        self.attn_balanced = True
+        self._gemm_mode = rc.gemm_engine
         # range guard (csrc/split.h): frames whose split-f16 activations left the f16 range are re-run on the exact-f32
-        # engines; counted here (encode side, decode side), CRA5_RANGE_GUARD=0 turns the re-run into an error
+        # engines; counted here (encode side, decode side); range_guard False turns the re-run into an error
         self.range_fallbacks = [0, 0]
-        self.range_guard = os.environ.get("CRA5_RANGE_GUARD", "1") != "0"
+        self.range_guard = rc.range_guard
         # "fp32" (default): 3-product split, fp32-accurate.  "f16": BASELINE.json configs[4] -
         # g_a / g_s projections and attention use plain f16 operands (1 MFMA per product, fp32
         # accumulate); the hyper-prior / GaussianConditional side stays fp32-accurate so that
@@ -313,15 +317,11 @@ class VAEformer(nn.Module):
         self.phase_log = None
         # optional log of the host (rANS) phases: a list receives ("enc" | "dec_z" | "dec_y", seconds) per frame; None = off
         self.host_log = None
-        self.precision = os.environ.get("CRA5_PRECISION", "fp32")
-        if self.precision not in ("fp32", "f16"):
-            raise ValueError("CRA5_PRECISION must be 'fp32' or 'f16'")
-        # reduced-precision mode: "plain" (default, round 5) - activations and weights of g_a / g_s travel as PLAIN f16
-        # rows wherever the consuming kernel takes them (full 128-byte lines per k-step: -13..-18 % per GEMM launch,
-        # bit-identical results); "split" keeps the hi planes of split rows (rounds 1-4; A / B runs, tests)
-        self.f16_layout = os.environ.get("CRA5_F16_LAYOUT", "plain")
-        if self.f16_layout not in ("plain", "split"):
-            raise ValueError("CRA5_F16_LAYOUT must be 'plain' or 'split'")
+        self.precision = rc.precision
+        # reduced-precision mode: "plain" (round 5) - activations and weights of g_a / g_s travel as PLAIN f16 rows wherever
+        # the consuming kernel takes them (full 128-byte lines per k-step: -13..-18 % per GEMM launch, bit-identical
+        # results); "split" keeps the hi planes of split rows (rounds 1-4; a test flips the attribute)
+        self.f16_layout = "plain"
         self._derived = {}
         self._derive_lock = threading.RLock()
         self._gpu_lock = threading.Lock()
@@ -329,22 +329,20 @@ class VAEformer(nn.Module):
         # gpu_slots = n > 0: at most n frames inside a GPU phase at a time (shared-stream mode only):
         # keeps a kernel's tail filled by another frame's blocks without letting ALL frames fall
         # into the host (rANS) phase together, which idles the GPU.  0 = unlimited.
-        self.gpu_slots = int(os.environ.get("CRA5_GPU_SLOTS", "3"))
-        # y symbols are resolved against the CDF tables by a device kernel (same byte stream)
-        self.resolve_on_gpu = os.environ.get("CRA5_RESOLVE_GPU", "1") != "0"
-        # decode side: uint8 CDF indexes / int16 symbols between device and host coder (same streams, same y_hat);
-        # CRA5_COMPACT_RECORDS=0 keeps the int32 records of the reference's interface
-        self.compact_records = os.environ.get("CRA5_COMPACT_RECORDS", "1") != "0"
-        # un-embed: GEMM epilogue scatters straight into the reconstruction (csrc/gemm_split_epilogue_unembed.inc);
-        # CRA5_FUSED_UNEMBED=0 keeps the GEMM -> column matrix -> overlap-add pair (A/B runs; bit-identical results)
-        self.fused_unembed = os.environ.get("CRA5_FUSED_UNEMBED", "1") != "0"
+        self.gpu_slots = rc.gpu_slots
+        # Bit-identical implementation alternatives, kept because tests compare the two forms (attributes, no environment
+        # variable): y symbols resolved against the CDF tables by a device kernel (same byte stream) | on the host;
+        # decode side: uint8 CDF indexes / int16 symbols between device and host coder | the int32 records of the
+        # reference's interface; un-embed: GEMM epilogue scatters straight into the reconstruction
+        # (csrc/gemm_split_epilogue_unembed.inc) | GEMM -> column matrix -> overlap-add
+        self.resolve_on_gpu = True
+        self.compact_records = True
+        self.fused_unembed = True
         self._gpu_sem = None
-        # order of the frames waiting for a GPU-phase slot: "g1" (default) encode-side phases first, "g3" decode-side
-        # phases first, "fifo" arrival order (see _SlotGate)
-        self.gpu_prio = os.environ.get("CRA5_GPU_PRIO", "g1")
-        # the ~1 ms h_s phase between the two host phases of a decode does not queue for a slot
-        self.light_bypass = os.environ.get("CRA5_LIGHT_BYPASS", "1") != "0"
-        self.light_priority = os.environ.get("CRA5_LIGHT_PRIORITY", "1") != "0"
+        # (frames waiting for a GPU-phase slot: encode-side phases first - see _SlotGate; the ~1 ms h_s phase between the
+        # two host phases of a decode does not queue for a slot and runs on a high-priority stream.  Rounds 3-5 carried
+        # environment switches for the alternatives - decode-side first / arrival order, queueing h_s - which measured
+        # slower every time: profiles/EXPERIMENTS.md)
         self._tls = threading.local()  # per-thread workspaces: one frame pipeline per thread/stream
         self.eval()
 
@@ -852,17 +850,17 @@ class VAEformer(nn.Module):
         t0 = time.perf_counter() if log is not None else 0.0
         if not self.gpu_exclusive:
             sem = None
-            if self.gpu_slots > 0 and not (light and self.light_bypass):
+            if self.gpu_slots > 0 and not light:
                 sem = self._gpu_sem
                 if sem is None or sem[0] != self.gpu_slots:
                     with self._gpu_lock:
                         sem = self._gpu_sem
                         if sem is None or sem[0] != self.gpu_slots:
                             sem = self._gpu_sem = (self.gpu_slots, _SlotGate(self.gpu_slots))
-                sem[1].acquire(prio if self.gpu_prio == "g1" else (-prio if self.gpu_prio == "g3" else 0))
+                sem[1].acquire(prio)
             t1 = time.perf_counter() if log is not None else 0.0
             try:
-                if light and self.light_priority:
+                if light:
                     # the ~1 ms h_s phase sits between a frame's two host phases: on a high-priority
                     # HIP stream its small kernels are scheduled ahead of the other frames' queued
                     # blocks instead of behind them (the previous phase of this frame ended with a

@@ -55,7 +55,8 @@ def _find_checkpoint(architecture, quality):
     weights in the reference either (zoo/image.py:290 raises for them)."""
     if architecture != "vaeformer-pretrained":
         return None
-    cands = [os.environ.get("CRA5_WEIGHTS")]
+    from .config import RuntimeConfig
+    cands = [RuntimeConfig.from_env().weights or None]       # CRA5_WEIGHTS (cra5_amd/config.py)
     name = _CKPT_NAMES.get(quality)
     if name:
         cands.append(os.path.join(torch.hub.get_dir(), "checkpoints", name))

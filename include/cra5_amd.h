@@ -200,7 +200,11 @@ int cra5_window_attention_f32(const float *qkv, const float *pad_row, float *out
  * attention); a window that is not the whole grid must have <= 1152 tokens (CRA5_ERR_ARG otherwise);
  * other shapes use cra5_window_attention_f32.  hi_only != 0: reduced-precision mode
  * (plain f16 q/k/v/p operands, 8 MFMAs per tile instead of 24; fp32 softmax statistics; only the hi plane of
- * out_split is written). */
+ * out_split is written): 1 = split rows, 3 = PLAIN f16 rows (qkv, the pad row and out_split: element n at half n, row
+ * pitches unchanged).  | CRA5_ATTN_PERSISTENT_UNITS: windows of >= 384 tokens run as persistent 12-wave work-groups
+ * walking (window, head) units instead of 4-wave work-groups (an alternative schedule kept for measurements: slower on
+ * MI355X; tokens of the key-split remainder units differ from the default schedule by fp32 rounding). */
+#define CRA5_ATTN_PERSISTENT_UNITS 4
 int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
                                 float *out, uint16_t *out_split, int out_kp, int C, int heads,
                                 int H, int W, int wh, int ww, float scale, int hi_only,

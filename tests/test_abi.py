@@ -65,7 +65,8 @@ def test_release_sources_carry_no_experiment_switches():
                "__x86_64__",
                "CRA5_RANGE_CHECK",           # `rangecheck` flavour: counts out-of-range split-f16 stores (same results)
                "CRA5_GEMM_TRACE",            # tools/gemm_trace.py: per-work-group timestamps (same results)
-               "CRA5_HY_SWEEP"}              # tools/hyper_gemm_sweep.sh: CRA5_HY_GEMM override of the small-GEMM shape
+               "CRA5_HY_SWEEP",              # tools/hyper_gemm_sweep.sh: CRA5_HY_GEMM override of the small-GEMM shape
+               "CRA5_TUNING_ENV"}            # variant builds: CRA5_GEMM_TILE / CRA5_ATT72_NW tile overrides (same results)
     csrc = os.path.join(ROOT, "cra5_amd", "csrc")
     seen = set()
     for f in sorted(os.listdir(csrc)):
@@ -82,3 +83,25 @@ def test_release_sources_carry_no_experiment_switches():
     from cra5_amd import build as B
     flags = " ".join(B.FLAVOURS["release"]["host"] + B.FLAVOURS["release"]["dev"] + sum(B.EXTRA.values(), []))
     assert "-D" not in flags, flags
+
+
+def test_product_library_reads_no_environment_variable():
+    """Round 6: settings come from ONE place, cra5_amd/config.py RuntimeConfig.from_env(); the native
+    library itself imports no getenv (the tile-override hooks of earlier rounds exist in -DCRA5_TUNING_ENV variant builds
+    only) and no other module of the package reads a CRA5_* setting from os.environ."""
+    import subprocess
+    from cra5_amd import build as B
+    lib = B.build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in und, [l for l in und.split("\n") if "getenv" in l]
+    import re as _re
+    pkg = os.path.join(ROOT, "cra5_amd")
+    allowed_elsewhere = {"CRA5_LIB",                                            # which library file: build matter (_lib.py)
+                         "CRA5_FORCE_DIST", "CRA5_DIST_BACKEND", "CRA5_SHARE_GPU", "CRA5_DIST_TIMEOUT_S",   # launcher / tests (dist.py)
+                         "CRA5_TEST_FREE_GIB", "CRA5_TEST_N_CPUS"}              # test hooks of the preflight
+    for f in sorted(os.listdir(pkg)):
+        if not f.endswith(".py") or f in ("config.py", "build.py"):
+            continue
+        src = open(os.path.join(pkg, f)).read()
+        for m in _re.finditer(r"environ[^\n]*?[\"'](CRA5_[A-Z0-9_]+)[\"']", src):
+            assert m.group(1) in allowed_elsewhere, (f, m.group(1))

@@ -314,3 +314,84 @@ def test_profiles_and_tools_readmes_match_the_directories():
     table = t.split("| script |", 1)[1]
     listed = set(re.findall(r"`([A-Za-z0-9_/]+\.(?:py|sh|hip))`", table)) - {"bench.py"}
     assert not [f for f in listed if f not in have], [f for f in listed if f not in have]
+
+
+def test_netcdf4_branch_through_a_stub_xarray(tmp_path, monkeypatch):
+    """The xarray branch of cra5_api._open_nc (what the reference itself does: cra5_api.py:203-208,
+    `xr.open_dataset(path, engine='netcdf4')`, `ds[name].data`, `ds.close()`) has never run in this image (no xarray, no
+    netCDF4).  A stub module with exactly the three members the branch uses makes it EXECUTE: the call signature, the
+    channel assembly on what it returns (levels in the file's own order, `tp` x 1000) and the close() calls are pinned;
+    the HDF5 decoding itself is xarray's job and stays untested offline."""
+    import sys
+    import types
+    import numpy as np
+    from cra5_amd.api import cra5_api
+    api = cra5_api(local_root=str(tmp_path), device="cpu", weights=VAEformer(0, **synth.thin_model_kwargs()))
+    H, W = 2, 3
+    rng = np.random.default_rng(9)
+    levels = np.array(api.total_levels, dtype=np.float64)[::-1].copy()
+    store, opened, closed = {}, [], []
+    for k, v in enumerate(api.vnames["pressure"]):
+        store[v] = rng.standard_normal((1, 37, H, W)).astype(np.float32) * (k + 1)
+    for v in api.vnames["single"]:
+        store[v] = rng.standard_normal((1, H, W)).astype(np.float32)
+    store["level"] = levels
+
+    class _Var:
+        def __init__(self, a):
+            self.data = a
+
+    class _DS:
+        def __init__(self, path):
+            self.path = path
+
+        def __getitem__(self, name):
+            return _Var(store[name])
+
+        def close(self):
+            closed.append(self.path)
+
+    def open_dataset(path, engine=None, **kw):
+        assert engine == "netcdf4" and not kw          # the reference's call, cra5_api.py:203-204
+        opened.append(path)
+        return _DS(path)
+    monkeypatch.setitem(sys.modules, "xarray", types.SimpleNamespace(open_dataset=open_dataset))
+    ts = "2024-06-01T02:00:00"
+    x = api.read_data_from_nc(ts)                      # (no file on disk: the stub never touches the path)
+    assert opened == [f"{tmp_path}/ERA5/2024/{ts}_pressure.nc", f"{tmp_path}/ERA5/2024/{ts}_single.nc"]
+    assert sorted(closed) == sorted(opened)
+    assert x.shape == (268, H, W) and x.dtype == np.float32
+    for ch in range(268):
+        name = api.channels_to_vname[ch]
+        if "_" in name and name.split("_")[0] in api.vnames["pressure"]:
+            v, lev = name.split("_")
+            want = store[v][0, list(levels).index(float(lev))]
+        else:
+            want = store[name][0] * (1000 if name == "tp" else 1)
+        assert np.array_equal(x[ch], want.astype(np.float32)), name
+
+
+def test_runtime_config_is_the_one_place_settings_come_from():
+    """cra5_amd/config.py: defaults < CRA5_* environment < explicit arguments; invalid values are refused at construction;
+    a model built with `runtime=` takes every setting from the object and none from the environment."""
+    from cra5_amd.config import RuntimeConfig
+    d = RuntimeConfig()
+    assert (d.precision, d.gemm_engine, d.attn_engine, d.range_guard, d.gpu_slots, d.inflight, d.link_serial) == \
+        ("fp32", "split", "split", True, 3, 12, True)
+    env = {"CRA5_PRECISION": "f16", "CRA5_GPU_SLOTS": "2", "CRA5_RANGE_GUARD": "0", "CRA5_LINK_SERIAL": "off",
+           "CRA5_WEIGHTS": "/x/y.pth", "CRA5_SWITCH_INTERVAL": "0.001", "CRA5_UNKNOWN_SWITCH": "1"}
+    e = RuntimeConfig.from_env(env)
+    assert (e.precision, e.gpu_slots, e.range_guard, e.link_serial, e.weights, e.switch_interval_s) == \
+        ("f16", 2, False, False, "/x/y.pth", 0.001)
+    assert RuntimeConfig.from_env(env, gpu_slots=5).gpu_slots == 5
+    assert e.replace(precision="fp32").precision == "fp32" and e.precision == "f16"
+    for bad in (dict(precision="bf16"), dict(gemm_engine="blas"), dict(attn_engine="x"), dict(inflight=0), dict(copy_threads=65)):
+        with pytest.raises(ValueError):
+            RuntimeConfig(**bad)
+    with pytest.raises(ValueError):
+        RuntimeConfig.from_env({"CRA5_GEMM": "cublas"})
+    assert set(RuntimeConfig.ENV) == {f for f in RuntimeConfig.__dataclass_fields__}
+    assert "set_by_environment" in d.describe() and d.describe()["precision"] == "fp32"
+    net = VAEformer(0, runtime=e.replace(gemm_engine="f32"), **synth.thin_model_kwargs())
+    assert (net.precision, net.gemm_mode, net.gpu_slots, net.range_guard) == ("f16", "f32", 2, False)
+    assert net.runtime.gemm_engine == "f32"

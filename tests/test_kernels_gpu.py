@@ -883,53 +883,35 @@ def test_global_attention_balanced_schedule_random_shapes(dev):
 
 
 def test_window_attention_persistent_units_opt_in(dev):
-    """Round 6 experiment kept as an opt-in (CRA5_ATTN_WINDOWS=persistent, read once per process -> a subprocess): windowed
-    launches as persistent 12-wave work-groups walking (window, head) units, the six left-over wave-tiles of a 576-token
-    window run as a key-SPLIT unit whose two halves are merged through LDS.  Same tests as the product path: fp32-accurate
-    form against float64 at the exact-f32 kernel's accuracy class, the three window shapes (48 x 12: padded windows),
-    both reduced-precision layouts finite and within their class."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-from cra5_amd import ops, synth
-from oracle import torch_ref as R
-dev = torch.device("cuda:0")
-H, W, C, heads = 72, 144, 128, 2
-g = torch.Generator().manual_seed(11)
-x = torch.randn(1, H * W, C, generator=g)
-sd = synth.fill_state_dict({"attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,), "attn.proj.weight": (C, C), "attn.proj.bias": (C,)}, seed=21)
-sd["attn.qkv.weight"] *= 3.0
-xd = {k: v.double() for k, v in sd.items()}
-rm = lambda a, b: float(torch.sqrt(torch.mean((a.double().cpu() - b.double().cpu()) ** 2)))
-for ws in ((24, 24), (12, 48), (48, 12)):
-    ref = R.attention_window(x.double(), xd, "attn", heads, H, W, ws)
+    """Round 6 experiment kept as an opt-in flag of the C ABI (CRA5_ATTN_PERSISTENT_UNITS): windowed launches as persistent
+    12-wave work-groups walking (window, head) units, the six left-over wave-tiles of a 576-token window run as a key-SPLIT
+    unit whose two halves are merged through LDS.  Same bounds as the product path: fp32-accurate form against float64 at the
+    exact-f32 kernel's accuracy class on the three window shapes (48 x 12: padded windows); tokens of FULL units are
+    bit-identical to the default schedule (same arithmetic), the others differ by fp32 rounding; both reduced-precision
+    layouts stay in their class."""
+    H, W, C, heads = 72, 144, 128, 2
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, H * W, C, generator=g)
+    sd = synth.fill_state_dict({"attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,), "attn.proj.weight": (C, C),
+                                "attn.proj.bias": (C,)}, seed=21)
+    sd["attn.qkv.weight"] *= 3.0
+    xd = {k: v.double() for k, v in sd.items()}
     xs = ops.split_f16(x[0].to(dev))
     qkv_s = ops.SplitMat.empty(H * W, 3 * C, dev)
-    ops.gemm_nt_split(xs, ops.split_f16(sd["attn.qkv.weight"].to(dev), "auto"), bias=sd["attn.qkv.bias"].to(dev), out_split=qkv_s, want_f32=False)
+    ops.gemm_nt_split(xs, ops.split_f16(sd["attn.qkv.weight"].to(dev), "auto"), bias=sd["attn.qkv.bias"].to(dev),
+                      out_split=qkv_s, want_f32=False)
     pad_s = ops.split_f16(sd["attn.qkv.bias"].to(dev).reshape(1, -1))
-    att = ops.SplitMat.empty(H * W, C, dev, zero=True)
-    ops.window_attention_split(qkv_s, pad_s, heads, H, W, ws[0], ws[1], out_split=att)
-    out = ops.gemm_nt_split(att, ops.split_f16(sd["attn.proj.weight"].to(dev), "auto"), bias=sd["attn.proj.bias"].to(dev))
-    e = rm(out, ref[0])
-    att16 = ops.SplitMat.empty(H * W, C, dev, zero=True)
-    o16 = torch.empty(H * W, C, device=dev)
-    ops.window_attention_split(qkv_s, pad_s, heads, H, W, ws[0], ws[1], out=o16, out_split=att16, hi_only=True)
-    o32 = torch.empty(H * W, C, device=dev)
-    ops.window_attention_split(qkv_s, pad_s, heads, H, W, ws[0], ws[1], out=o32)
-    e16 = rm(o16, o32) / rm(o32, torch.zeros_like(o32))
-    print("RESULT", ws, e, e16, bool(torch.isfinite(o16).all()))
-''' % root
-    env = dict(os.environ, CRA5_ATTN_WINDOWS="persistent")
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
-    rows = [l.split() for l in p.stdout.split("\n") if l.startswith("RESULT")]
-    assert len(rows) == 3, p.stdout
-    for l in p.stdout.split("\n"):
-        if l.startswith("RESULT"):
-            e, e16, fin = l.split()[-3:]
-            assert float(e) < 4e-6, l               # the product path's bound (test_window_attention_split_f16)
-            assert float(e16) < 2e-3 and fin == "True", l
+    for ws in ((24, 24), (12, 48), (48, 12)):
+        ref = R.attention_window(x.double(), xd, "attn", heads, H, W, ws)
+        att = ops.SplitMat.empty(H * W, C, dev, zero=True)
+        o_p = torch.empty(H * W, C, device=dev)
+        ops.window_attention_split(qkv_s, pad_s, heads, H, W, ws[0], ws[1], out=o_p, out_split=att, persistent_units=True)
+        out = ops.gemm_nt_split(att, ops.split_f16(sd["attn.proj.weight"].to(dev), "auto"), bias=sd["attn.proj.bias"].to(dev))
+        assert rmse(out, ref[0]) < 4e-6                      # the product path's bound (test_window_attention_split_f16)
+        o_c = torch.empty(H * W, C, device=dev)
+        ops.window_attention_split(qkv_s, pad_s, heads, H, W, ws[0], ws[1], out=o_c)
+        same = float((o_p == o_c).float().mean())
+        assert same >= 0.6 and float((o_p - o_c).abs().max()) < 1e-5, (ws, same)   # 12 of 18 wave-tiles per window run FULL units
+        o16 = torch.empty(H * W, C, device=dev)
+        ops.window_attention_split(qkv_s, pad_s, heads, H, W, ws[0], ws[1], out=o16, hi_only=True, persistent_units=True)
+        assert torch.isfinite(o16).all() and rmse(o16, o_c) < 2e-3 * float(o_c.double().pow(2).mean().sqrt())

@@ -870,7 +870,7 @@ def test_full268_reduced_precision_mode(big, dev, golden_dir):
 
 def test_reduced_precision_plain_layout_equals_the_split_layout(big, thin, dev):
     """Round 5: in the reduced-precision mode activations / weights of g_a and g_s travel as PLAIN f16 rows wherever the
-    consuming kernel takes them (CRA5_F16_LAYOUT=plain, the default) - a different memory layout of the same f16 values:
+    consuming kernel takes them (VAEformer.f16_layout = "plain", the default) - a different memory layout of the same f16 values:
     y, x_hat and the streams equal those of the split layout (rounds 1-4) BIT FOR BIT, on the 268 model (every GEMM of
     a block plain) and on the thin one (only its fc1 / fc2 are wide enough: the mixed case)."""
     for net, C, L in ((big, 268, 256), (thin, 8, 16)):

@@ -1,7 +1,7 @@
 """Windowed attention, A / B of the launch forms (GPU box): run once per form, the second run compares with the first.
 
-  python tools/attn_window_ab.py gpurun_out/r06/attn_win                                   # 4-wave work-groups (the product path)
-  CRA5_ATTN_WINDOWS=persistent python tools/attn_window_ab.py gpurun_out/r06/attn_win      # persistent 12-wave units (round 6 experiment)
+  python tools/attn_window_ab.py gpurun_out/r06/attn_win                 # 4-wave work-groups (the product path)
+  python tools/attn_window_ab.py gpurun_out/r06/attn_win persistent      # persistent 12-wave units (round 6 experiment)
 
 Per window shape of the model (24 x 24, 12 x 48, 48 x 12 on the 72 x 144 grid, 16 heads x 64) and per precision form
 (fp32-accurate, reduced precision on split rows, on plain rows): us per launch (HIP events over 200 back-to-back launches)
@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from cra5_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-form = "persistent" if os.environ.get("CRA5_ATTN_WINDOWS", "").startswith("p") else "classic"
+form = "persistent" if len(sys.argv) > 2 and sys.argv[2].startswith("p") else "classic"
 prefix = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/attn_win"
 H, W, C, heads = 72, 144, 1024, 16
 N = H * W
@@ -42,7 +42,8 @@ for name, (wh, ww) in (("w24x24", (24, 24)), ("w12x48", (12, 48)), ("w48x12", (4
                              ("f16_plain", (qp, pp, dict(hi_only=True)))):
         o32 = torch.empty(N, C, device=dev) if prec == "fp32" else None
         osp = ops.SplitMat.empty(N, C, dev, zero=True)
-        fn = lambda: ops.window_attention_split(a, p, heads, H, W, wh, ww, out=o32, out_split=osp, **kw)  # noqa: E731
+        fn = lambda: ops.window_attention_split(a, p, heads, H, W, wh, ww, out=o32, out_split=osp,  # noqa: E731
+                                                persistent_units=form == "persistent", **kw)
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
