@@ -422,6 +422,64 @@ def error_line(exc, stage):
 STAGE = ["startup"]     # where main() is (the error line names it)
 
 
+def single_frame_budget(api, host_frame, reps=4):
+    """Where the time of ONE serial call pair of the reference-named API goes (test.py:14-45 in the
+    reference): encode_era5_as_bin(host array) = H2D | G1 (finite probe, g_a) | G1b (h_a, h_s, GaussianConditional, records
+    to the host) | H1 (rANS z + y) | .bin write; decode_from_bin = .bin read | H2z (rANS z) | G2 (h_s, CDF indexes to the
+    host) | H2y (rANS y) | G3 (de-quantise, g_s, probe).  Phases from VAEformer.phase_log / host_log + wall-clock stamps
+    of the API calls; `other` = what the stamps do not cover (Python between the phases, stream syncs).  Median of the
+    reps after the first."""
+    import tempfile
+    import shutil
+    net = api.net
+    tmp = tempfile.mkdtemp(prefix="cra5_budget_")
+    ts = "2024-06-01T00:00:00"
+    rows = []
+    try:
+        for _ in range(reps):
+            net.phase_log, net.host_log = [], []
+            orig_frame = api._frame
+            stamp = {}
+
+            def timed_frame(time_stamp, data, _o=orig_frame):
+                t = time.perf_counter()
+                r = _o(time_stamp, data)
+                torch.cuda.current_stream().synchronize()
+                stamp["h2d"] = time.perf_counter() - t
+                return r
+            api._frame = timed_frame
+            try:
+                t0 = time.perf_counter()
+                enc = api.encode_era5_as_bin(ts, save_root=tmp + "/CRA5", data=host_frame)
+                t1 = time.perf_counter()
+            finally:
+                api._frame = orig_frame
+            g_enc = [e[3] - e[2] for e in net.phase_log]            # GPU phases (start -> end incl. the closing sync)
+            h_enc = dict(net.host_log)
+            net.phase_log, net.host_log = [], []
+            t2 = time.perf_counter()
+            api.decode_from_bin(ts, custom_path=enc["save_path"], return_format="de_normalized")
+            t3 = time.perf_counter()
+            g_dec = [e[3] - e[2] for e in net.phase_log]
+            h_dec = dict(net.host_log)
+            row = {"encode_total": t1 - t0, "h2d": stamp.get("h2d", 0.0),
+                   "g1_g_a": g_enc[0] if g_enc else 0.0, "g1b_latent_side": sum(g_enc[1:]),
+                   "h1_rans_encode": h_enc.get("enc", 0.0), "bin_write": enc["saving_time"],
+                   "decode_total": t3 - t2, "h2z_rans_decode_z": h_dec.get("dec_z", 0.0),
+                   "g2_h_s_indexes": g_dec[0] if g_dec else 0.0, "h2y_rans_decode_y": h_dec.get("dec_y", 0.0),
+                   "g3_g_s": sum(g_dec[1:])}
+            row["encode_other"] = row["encode_total"] - sum(row[k] for k in ("h2d", "g1_g_a", "g1b_latent_side", "h1_rans_encode", "bin_write"))
+            row["decode_other"] = row["decode_total"] - sum(row[k] for k in ("h2z_rans_decode_z", "g2_h_s_indexes", "h2y_rans_decode_y", "g3_g_s"))
+            rows.append(row)
+    finally:
+        net.phase_log = net.host_log = None
+        shutil.rmtree(tmp, ignore_errors=True)
+    use = rows[1:] or rows
+    med = {k: 1e3 * sorted(r[k] for r in use)[len(use) // 2] for k in rows[0]}
+    med["frames_per_s"] = 1e3 / (med["encode_total"] + med["decode_total"])
+    return med
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under
     torch.distributed.run (one process per GPU; standalone rendezvous on 127.0.0.1, port chosen by the launcher).  stdout / stderr are
@@ -1093,8 +1151,13 @@ def main():
                 td.append(time.perf_counter() - t1)
                 te.append(t1 - t0)
             e, d = sorted(te[1:])[1], sorted(td[1:])[1]
+            try:
+                budget = single_frame_budget(api, host)
+            except Exception as ex:  # noqa: BLE001
+                budget = {"error": repr(ex)}
             result["api_single_frame"] = {
                 "value": 1.0 / (e + d), "unit": "frames/s", "encode_s": e, "decode_s": d, "threads": 1,
+                "budget_ms": budget,
                 "what": "cra5_api.encode_era5_as_bin(data=host fp32 array) + decode_from_bin('de_normalized'), serial, "
                         "H2D of the 1.11 GB frame and .bin write / read included, x_hat left on the device as the "
                         "reference does (tools/api_testpy_loop.py times every call of the reference's test.py loop)"}

@@ -63,6 +63,16 @@ __device__ __forceinline__ int token_of(const WinGeom &g, int wr, int wc, int t)
   return (gr < g.H && gc < g.W) ? gr * g.W + gc : -1;
 }
 
+#ifdef CRA5_ATTN_TRACE
+// debug build only (tools/attn_trace.py): per work-group (classic) / per unit (PERSIST) wall-clock stamps {start, key loop
+// start, key loop end, end}, the key tiles of the unit and the shader cycles between start and end
+__device__ unsigned long long g_attn_trace[6 * 8192];
+#define CRA5_ATRACE(SLOT, VAL)                                                                          \
+  if (threadIdx.x == 0 && atrace_idx < 8192) g_attn_trace[atrace_idx * 6 + (SLOT)] = (VAL);
+#else
+#define CRA5_ATRACE(SLOT, VAL)
+#endif
+
 constexpr int HD = 64;
 constexpr int KS = 72;   // K LDS row stride (halves): 144 B
 constexpr int VS = 96;   // V LDS row stride (halves): 192 B - see the ds_read_b64_tr_b16 note in the kernel
@@ -131,8 +141,21 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   constexpr int NT = NW * 64;
   constexpr int PPR = PLAIN ? 8 : 16;             // 16-byte pieces per K (or V) row of one head: 64 d x (hi | hi + lo)
   constexpr int PIECES = 32 * PPR;                // 16-byte pieces per K (or V) tile
-  constexpr int NGRP = PERSIST ? 2 : 1;           // wave groups with a K / V tile of their own (SPLIT units)
-  constexpr int STG = (NGRP * PIECES + NT - 1) / NT;
+  constexpr int STG = (PIECES + NT - 1) / NT;
+  // PERSIST stages K / V by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into a ring of NSTG
+  // stages per wave group, so that a tile is requested THREE key steps before its scores are due - one step of prefetch
+  // (registers) left all 12 waves of the CU waiting for the slowest L2-missing load at every barrier.  A stage is the K
+  // image followed by the V image, rows UN-padded (a DMA instruction writes 1 KB linearly: 4 split rows / 8 plain rows),
+  // 16-byte pieces XOR-swizzled through the per-lane SOURCE address so that the fragment reads stay conflict-free:
+  //   K (ds_read_b128, 16 consecutive rows per cycle):   piece ^ (row & 15)            [plain: piece ^ ((row >> 1) & 7)]
+  //   V (ds_read_b64_tr_b16, 4 consecutive rows x 64 B): piece ^ 4 (row & 3)           [plain: piece ^ 4 ((row >> 1) & 1)]
+  constexpr int ROWH = PLAIN ? 64 : 128;          // halves per K / V row image
+  constexpr int KIMG = 32 * ROWH;                 // halves per K (or V) tile image
+  constexpr int STAGE_H = 2 * KIMG;               // K image | V image
+  constexpr int NSTG = 4;
+  constexpr int NIG = PLAIN ? 8 : 16;             // DMA instructions per stage and wave group (K: first half, V: second)
+  constexpr int RPI = PLAIN ? 8 : 4;              // rows per DMA instruction
+  constexpr int NPW = (2 * NIG + NW - 1) / NW;    // most DMA instructions a wave issues per stage (SPLIT units: two groups)
 
   // [K hi][K lo] : 32 x KS ;  [V hi][V lo] : 32 x VS (row-major like K, transposed by the READ)
   constexpr int KPL = 32 * KS + 32;   // K plane stride (halves): +64 B so hi/lo planes hit different bank halves
@@ -140,9 +163,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   // two K buffers and two V^T buffers: tile j+1's scores are issued to the matrix pipe BEFORE
   // the softmax of tile j, so K runs one tile ahead of V; one barrier per key tile.
   constexpr int KBUF = 2 * KPL, VBUF = 2 * VPL;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[NGRP * (2 * KBUF + 2 * VBUF)];
-  unsigned short *Ks = lds;                       // group gq's two K buffers at Ks + gq * 2 * KBUF
-  unsigned short *Vt = lds + NGRP * 2 * KBUF;     // ...            V buffers at Vt + gq * 2 * VBUF
+  __shared__ __attribute__((aligned(16))) unsigned short lds[PERSIST ? 2 * NSTG * STAGE_H : 2 * KBUF + 2 * VBUF];
+  unsigned short *Ks = lds;                       // (PERSIST: wave group g's ring at lds + g * NSTG * STAGE_H)
+  unsigned short *Vt = lds + 2 * KBUF;
   // windowed launches: byte offset (from qkv) of every window token's row, pad tokens -> the pad
   // row; built once per block so that the per-tile staging needs no division / multiply.
   constexpr int TAB = GLOBAL ? 1 : MAX_WIN_TOKENS;
@@ -265,6 +288,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       tab[t] = (tok >= 0) ? (long long)tok * ldq * 2 : pad_delta;
     }
   }
+#ifdef CRA5_ATTN_TRACE
+  const int atrace_idx = PERSIST ? (int)blockIdx.x * 4 + seg : (GLOBAL ? 8192 : (int)blockIdx.x);
+  const unsigned long long atrace_c0 = clock64();
+#endif
+  CRA5_ATRACE(0, wall_clock64());
   // SPLIT unit: wave group gw = wave / (NW / 2) runs tiles tile0 + wave % (NW / 2) over key tiles [gw * n_tiles, + n_tiles)
   const int gw = (PERSIST && split) ? wave / (NW / 2) : 0;
   const int wq = (PERSIST && split) ? wave - gw * (NW / 2) : wave;
@@ -324,11 +352,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   constexpr bool TWO = STG == 2;
   // thread -> (row, piece) of its two K pieces and (row, two pieces) of V; indexes past the tile
   // (NW = 6: 384 threads x 2 > 512 pieces) are clamped: loaded redundantly, never stored.
-  // PERSIST: rows 32..63 of the piece index are wave group 1's tile (SPLIT units only; n_pieces = PIECES otherwise)
-  const int n_pieces = (PERSIST && split) ? 2 * PIECES : PIECES;
-  const int krow0 = PERSIST ? ((tid / PPR) & 31) : min(tid / PPR, 31), krow1 = PERSIST ? (((tid + NT) / PPR) & 31) : min((tid + NT) / PPR, 31);
-  const int kgrp0 = PERSIST ? ((tid / PPR) >> 5) & 1 : 0, kgrp1 = PERSIST ? (((tid + NT) / PPR) >> 5) & 1 : 0;
-  const int ktile0 = kgrp0 * (j1 - j0), ktile1 = kgrp1 * (j1 - j0);       // first key tile of the piece's wave group
+  const int krow0 = min(tid / PPR, 31), krow1 = min((tid + NT) / PPR, 31);
   const long kcol = koff + (tid % PPR) * 8;                                 // halves
   const long vcol = voff + (tid % PPR) * 8;
   // whole-grid launches walk three running row pointers (+32 rows per tile); windowed ones look
@@ -342,8 +366,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(qkv) + tab[(JJ)*32 + (ROW)])
   // (waves whose pieces fall past the 512 of a tile - 4 of 12, or the second piece of 4 of 6 - skip the
   // loads and their address arithmetic altogether: the conditions are wave-uniform)
-  const bool stage0 = PERSIST ? (tid < n_pieces) : ((NT <= PIECES) || (tid < PIECES));
-  const bool stage1 = TWO && (tid + NT < (PERSIST ? n_pieces : PIECES));
+  const bool stage0 = !PERSIST && ((NT <= PIECES) || (tid < PIECES));   // (PERSIST: no register staging at all)
+  const bool stage1 = !PERSIST && TWO && (tid + NT < PIECES);
 #define CRA5_K_LOAD(J)                                                                    \
   if (stage0) {                                                                           \
     if (GLOBAL) {                                                                         \
@@ -354,8 +378,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       kq1 += st_;                                                                         \
     } else {                                                                              \
       const int jj_ = min((J), n_tiles - 1);                                              \
-      sk0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile0, krow0) + kcol);       \
-      if (stage1) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile1, krow1) + kcol); \
+      sk0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + kcol);                \
+      if (stage1) sk1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + kcol);    \
     }                                                                                     \
   }
 #define CRA5_V_LOAD(J)                                                                    \
@@ -368,30 +392,28 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       vq1 += st_;                                                                         \
     } else {                                                                              \
       const int jj_ = min((J), n_tiles - 1);                                              \
-      sv0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile0, krow0) + vcol);       \
-      if (stage1) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_ + ktile1, krow1) + vcol); \
+      sv0 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow0) + vcol);                \
+      if (stage1) sv1 = *reinterpret_cast<const uint4 *>(CRA5_ROW(jj_, krow1) + vcol);    \
     }                                                                                     \
   }
   // piece -> (chunk = piece>>3, plane = (piece>>2)&1, d0 = 32*chunk + 8*(piece&3))
 #define CRA5_K_STORE1(P, BUF)                                                             \
   {                                                                                       \
     const int idx = tid + (P)*NT;                                                         \
-    if (idx < n_pieces) {                                                                 \
-      const int row_ = idx / PPR, piece = idx % PPR;                                      \
-      const int row = PERSIST ? (row_ & 31) : row_, gq_ = PERSIST ? (row_ >> 5) : 0;      \
+    if (!PERSIST && idx < PIECES) {                                                       \
+      const int row = idx / PPR, piece = idx % PPR;                                       \
       const int plane = PLAIN ? 0 : (piece >> 2) & 1, d0 = PLAIN ? 8 * piece : 32 * (piece >> 3) + 8 * (piece & 3); \
-      *reinterpret_cast<uint4 *>(Ks + gq_ * 2 * KBUF + (BUF)*KBUF + plane * KPL + row * KS + d0) = sk##P;  \
+      *reinterpret_cast<uint4 *>(Ks + (BUF)*KBUF + plane * KPL + row * KS + d0) = sk##P;  \
     }                                                                                     \
   }
 #define CRA5_K_STORE(BUF) { CRA5_K_STORE1(0, BUF) if (TWO) CRA5_K_STORE1(1, BUF) }
 #define CRA5_V_STORE1(P, BUF)                                                             \
   {                                                                                       \
     const int idx = tid + (P)*NT;                                                         \
-    if (idx < n_pieces) {                                                                 \
-      const int row_ = idx / PPR, piece = idx % PPR;                                      \
-      const int row = PERSIST ? (row_ & 31) : row_, gq_ = PERSIST ? (row_ >> 5) : 0;      \
+    if (!PERSIST && idx < PIECES) {                                                       \
+      const int row = idx / PPR, piece = idx % PPR;                                       \
       const int plane = PLAIN ? 0 : (piece >> 2) & 1, d0 = PLAIN ? 8 * piece : 32 * (piece >> 3) + 8 * (piece & 3); \
-      *reinterpret_cast<uint4 *>(Vt + gq_ * 2 * VBUF + (BUF)*VBUF + plane * VPL + row * VS + d0) = sv##P;  \
+      *reinterpret_cast<uint4 *>(Vt + (BUF)*VBUF + plane * VPL + row * VS + d0) = sv##P;  \
     }                                                                                     \
   }
 #define CRA5_V_STORE(BUF) { CRA5_V_STORE1(0, BUF) if (TWO) CRA5_V_STORE1(1, BUF) }
@@ -402,8 +424,10 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     f32x16 acc_;                                                                          \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) acc_[r] = 0.f;                         \
     _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                    \
-      const half8 kh = *reinterpret_cast<const half8 *>(k_base + (KB)*KBUF + 16 * st);    \
-      const half8 kl = *reinterpret_cast<const half8 *>(k_base + (KB)*KBUF + KPL + 16 * st); \
+      const half8 kh = PERSIST ? *reinterpret_cast<const half8 *>(ring + (KB)*STAGE_H + koffs[0][st])      \
+                               : *reinterpret_cast<const half8 *>(k_base + (KB)*KBUF + 16 * st);            \
+      const half8 kl = PERSIST ? *reinterpret_cast<const half8 *>(ring + (KB)*STAGE_H + koffs[PLAIN ? 0 : 1][st]) \
+                               : *reinterpret_cast<const half8 *>(k_base + (KB)*KBUF + KPL + 16 * st);      \
       if (!HI) {                                                                          \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[st], acc_, 0, 0, 0);         \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[st], acc_, 0, 0, 0);         \
@@ -426,14 +450,14 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
 #define CRA5_MFMA_FROM(D, A, B, C) (D) = (C)
 #endif
 
-  const unsigned short *k_base = Ks + gw * 2 * KBUF + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
+  const unsigned short *k_base = Ks + l31 * KS + 8 * h;          // + buf*KBUF + plane*KPL + 16*s
   // V^T fragments (A operand: row d = l31, 8 keys per lane) come out of the ROW-MAJOR V image through
   // ds_read_b64_tr_b16: inside each 16-lane group, lane l' receives element (l' & 3) of the 8-byte
   // slots addressed by lanes (l' >> 2) + {0, 4, 8, 12} (probed: tools/probes/tr_probe.hip).  Lane l'
   // therefore ADDRESSES V[kbase + (l' >> 2)][d0 + 4 (l' & 3) ..+3] and RECEIVES V[kbase + 0..3][d0 + l'],
   // d0 = 16 ((lane >> 4) & 1): four consecutive keys of its own d.  Row stride 192 B puts the four
   // key rows x two d-halves of a 32-lane LDS cycle on 8 disjoint 8-bank ranges (conflict-free).
-  const unsigned short *v_base = Vt + gw * 2 * VBUF + (4 * h + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const unsigned short *v_base = Vt + (4 * h + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   // + buf*VBUF + plane*VPL + (16*t + 8*a)*VS + 32*dt
 
   // cross-half max: lanes l and l+32 own the two halves of one query's 32 scores
@@ -479,6 +503,94 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   })
 #endif
 
+  // ---- PERSIST: the LDS-DMA ring of this unit ---------------------------------------------------------------------
+  // fragment read offsets (halves) inside a stage: K row l31, logical piece P(plane, st) at P ^ swizzle(row); V row
+  // 4 h + rr (+ 16 t + 8 a as an immediate), piece Pv(plane, dt) ^ swizzle(row), the lane's 8-byte half of it
+  const unsigned short *ring = lds + gw * NSTG * STAGE_H;
+  int koffs[2][4], voffs[2][2];
+  {
+    const int swk = PLAIN ? ((l31 >> 1) & 7) : (l31 & 15);
+    const int rr = (lane & 15) >> 2, b_ = (lane >> 4) & 1, c_ = lane & 3;
+    const int swv = PLAIN ? 4 * (rr >> 1) : 4 * rr;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int P = PLAIN ? 2 * st + h : 8 * (st >> 1) + 4 * pl + 2 * (st & 1) + h;
+        koffs[pl][st] = l31 * ROWH + ((P ^ swk) << 3);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int Pv = PLAIN ? 4 * dt + 2 * b_ + (c_ >> 1) : 8 * dt + 4 * pl + 2 * b_ + (c_ >> 1);
+        voffs[pl][dt] = KIMG + (4 * h + rr) * ROWH + ((Pv ^ swv) << 3) + 4 * (c_ & 1);
+      }
+    }
+  }
+  // DMA instruction q = wave + NW n of a stage: wave group q / NIG, K (first half) or V, rows RPI i .. of the tile; lane l
+  // fetches the logical piece that belongs into physical slot l % PPR of row l / PPR.  dq_*: what stays fixed for the unit.
+  const int wave_s = PERSIST ? __builtin_amdgcn_readfirstlane(wave) : 0;
+  const int ni_unit = (PERSIST && split) ? 2 * NIG : NIG;
+  int dq_row[NPW], dq_tile[NPW], n_w = 0;
+  unsigned dq_col[NPW], dq_dst[NPW];
+  if (PERSIST) {
+    const unsigned lds_b = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned short *)lds);
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+      const int q = wave_s + NW * n;
+      const int grp = q / NIG, qq = q - grp * NIG;
+      const int isv = qq >= NIG / 2 ? 1 : 0, i_ = qq - isv * (NIG / 2);
+      const int r_ = RPI * i_ + lane / PPR, pp = lane % PPR;
+      const int sw = isv ? (PLAIN ? 4 * ((r_ >> 1) & 1) : 4 * (r_ & 3)) : (PLAIN ? ((r_ >> 1) & 7) : (r_ & 15));
+      dq_row[n] = r_;
+      dq_tile[n] = grp * (j1 - j0);
+      dq_col[n] = (unsigned)((isv ? voff : koff) * 2) + (unsigned)((pp ^ sw) * 16);
+      dq_dst[n] = lds_b + (unsigned)((grp * NSTG * STAGE_H + isv * KIMG) * 2 + i_ * 1024);
+      n_w += (q < ni_unit) ? 1 : 0;
+    }
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRA5_DMA_ISSUE(T)                                                                 \
+  {                                                                                       \
+    const int jj_ = min((T), n_tiles - 1);                                                \
+    const unsigned slot_ = (unsigned)(((T) & (NSTG - 1)) * STAGE_H * 2);                  \
+    _Pragma("unroll") for (int n = 0; n < NPW; ++n) {                                     \
+      if (wave_s + NW * n < ni_unit) {                                                    \
+        const char *src_ = reinterpret_cast<const char *>(qkv) + tab[(jj_ + dq_tile[n]) * 32 + dq_row[n]] + dq_col[n]; \
+        const unsigned dst_ = dq_dst[n] + slot_;                                          \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"   \
+                     :: "s"(dst_), "v"(src_) : "memory", "m0");                           \
+      }                                                                                   \
+    }                                                                                     \
+  }
+  // own DMA instructions of the stages before the newest one have landed (vmcnt counts in issue order); LATER = 0: all
+#define CRA5_DMA_WAIT(LATER)                                                              \
+  {                                                                                       \
+    const int k_ = (LATER) ? n_w : 0;                                                     \
+    if (k_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         \
+    else if (k_ == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                    \
+    else if (k_ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                    \
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                 \
+  }
+#else
+#define CRA5_DMA_ISSUE(T) (void)dq_row, (void)dq_tile, (void)dq_col, (void)dq_dst
+#define CRA5_DMA_WAIT(LATER) (void)n_w
+#endif
+  static_assert(!PERSIST || NPW <= 3, "CRA5_DMA_WAIT is written out for at most three instructions per wave and stage");
+
+  f32x16 s_cur;
+  float mloc;
+  if (PERSIST) {
+    // prologue: stages 0, 1, 2 requested (every wave is past the barrier that published this unit's row table and has
+    // drained its own DMAs / stores of the previous unit); stages 0 and 1 must have landed before the first scores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CRA5_DMA_ISSUE(0);
+    if (n_tiles > 1) CRA5_DMA_ISSUE(1);
+    if (n_tiles > 2) CRA5_DMA_ISSUE(2);
+    CRA5_DMA_WAIT(n_tiles > 2);
+    __syncthreads();
+    CRA5_SCORES(s_cur, 0);
+    mloc = CRA5_TILE_MAX(s_cur);
+  } else {
   // prologue: K(0), V(0), K(1) resident; K(2), V(1) in flight; S(0) done
   CRA5_K_LOAD(0);
   CRA5_V_LOAD(0);
@@ -489,19 +601,22 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
   __syncthreads();
   CRA5_K_LOAD(2);
   CRA5_V_LOAD(1);
-  f32x16 s_cur;
   CRA5_SCORES(s_cur, 0);
-  float mloc = CRA5_TILE_MAX(s_cur);
+  mloc = CRA5_TILE_MAX(s_cur);
   // The end of iteration 0 re-fills K buffer 0 with tile 2: every wave must be done reading tile 0 from
   // it (a wave a whole iteration ahead of another is unlikely, not impossible).
   __syncthreads();
+  }
 
   // Waves past the end of the window (q_tok < 0 for all lanes) run the same instruction stream
   // on the pad row and store nothing: one code path, no divergent barriers.
   // One key tile; the loop below is unrolled by two with the score registers swapping roles, so that tile j+1's
   // scores never have to be copied into tile j's registers (8 v_mov_b64 per tile).
   auto key_tile = [&](const int j, f32x16 &s_cur, f32x16 &s_next) __attribute__((always_inline)) {
-    const int kb = (j + 1) & 1, vb = j & 1;
+    const int kb = PERSIST ? ((j + 1) & (NSTG - 1)) : ((j + 1) & 1), vb = PERSIST ? (j & (NSTG - 1)) : (j & 1);
+    // PERSIST: stage j + 3 goes into the slot stage j - 1 left at the last barrier (nothing is requested past the unit's
+    // last tile: the tail waits for everything instead)
+    if (PERSIST && j + 3 < n_tiles) CRA5_DMA_ISSUE(j + 3);
     // (a wave whose 32 queries all lie past the end of the window - half of the fifth 128-query work-group of a
     // 576-token window - only stages and synchronises: its MFMAs would be taken from the other waves of its SIMD)
     if (!IDLE_SKIP || wave_active) {
@@ -650,11 +765,12 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       half8 vh[2], vl[2];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const unsigned short *vp = v_base + vb * VBUF + 16 * t * VS + 32 * dt;
+        const unsigned short *vp = PERSIST ? ring + vb * STAGE_H + voffs[0][dt] + 16 * t * ROWH : v_base + vb * VBUF + 16 * t * VS + 32 * dt;
+        const unsigned short *vq = PERSIST ? ring + vb * STAGE_H + voffs[PLAIN ? 0 : 1][dt] + 16 * t * ROWH : vp + VPL;
         const half4 a0 = CRA5_TR_READ(vp);
-        const half4 a1 = CRA5_TR_READ(vp + 8 * VS);
-        const half4 b0 = CRA5_TR_READ(vp + VPL);
-        const half4 b1 = CRA5_TR_READ(vp + VPL + 8 * VS);
+        const half4 a1 = CRA5_TR_READ(vp + 8 * (PERSIST ? ROWH : VS));
+        const half4 b0 = CRA5_TR_READ(vq);
+        const half4 b1 = CRA5_TR_READ(vq + 8 * (PERSIST ? ROWH : VS));
         vh[dt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
         vl[dt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
@@ -672,12 +788,19 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     // K(j+2) -> the buffer tile j's scores came from (last read before the previous barrier),
     // V(j+1) -> the other V buffer (past the end: stale data into buffers nobody reads);
     // then start fetching K(j+3), V(j+2).
+    if (PERSIST) {
+      // stage j + 2 (the K tile of the next step's scores) was requested two steps ago: this wave's share of it has
+      // landed once at most its share of stage j + 3 - requested at the top of this step, if at all - is outstanding
+      CRA5_DMA_WAIT(j + 3 < n_tiles);
+    } else {
     CRA5_K_STORE(j & 1);
     CRA5_V_STORE((j + 1) & 1);
     CRA5_K_LOAD(j + 3);
     CRA5_V_LOAD(j + 2);
+    }
     __syncthreads();
   };
+  CRA5_ATRACE(1, wall_clock64());
   f32x16 s_alt;
   const int n_loop = n_tiles;
   int jt = 0;
@@ -686,6 +809,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     key_tile(jt + 1, s_alt, s_cur);
   }
   if (jt < n_loop) key_tile(jt, s_cur, s_alt);
+  CRA5_ATRACE(2, wall_clock64());
+  CRA5_ATRACE(4, (unsigned long long)n_tiles + ((PERSIST && split) ? 1000 : 0));
 
   if (PERSIST && split) {
     // merge of the two key halves of a SPLIT unit: wave group 1 parks (m, l) and its 32 accumulator registers in the K / V
@@ -793,6 +918,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
         }
       }
   }
+  CRA5_ATRACE(3, wall_clock64());
+  CRA5_ATRACE(5, clock64() - atrace_c0);
   }   // segments
   (void)tab_ready;
 }
@@ -1012,6 +1139,17 @@ static int attention_dispatch(const uint16_t *qkv_split, int qkv_kp, const uint1
   CRA5_ATT_GO(4, false, false);
 #undef CRA5_ATT_GO
 }
+
+#ifdef CRA5_ATTN_TRACE
+extern "C" int cra5_debug_attn_trace(unsigned long long *host, int n_rows) {
+  if (n_rows < 1 || n_rows > 8192) return CRA5_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return CRA5_ERR_ARG;
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_trace), sizeof(unsigned long long) * 6 * n_rows);
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_attn_trace)) == hipSuccess) hipMemset(p, 0, sizeof(unsigned long long) * 6 * 8192);
+  return rc;
+}
+#endif
 
 extern "C" int cra5_window_attention_split(const uint16_t *qkv_split, int qkv_kp, const uint16_t *pad_row_split,
                                            float *out, uint16_t *out_split, int out_kp, int C, int heads, int H,

@@ -65,6 +65,7 @@ def test_release_sources_carry_no_experiment_switches():
                "__x86_64__",
                "CRA5_RANGE_CHECK",           # `rangecheck` flavour: counts out-of-range split-f16 stores (same results)
                "CRA5_GEMM_TRACE",            # tools/gemm_trace.py: per-work-group timestamps (same results)
+               "CRA5_ATTN_TRACE",            # tools/attn_trace.py: per-work-group / per-unit timestamps of the windowed attention
                "CRA5_HY_SWEEP",              # tools/hyper_gemm_sweep.sh: CRA5_HY_GEMM override of the small-GEMM shape
                "CRA5_TUNING_ENV"}            # variant builds: CRA5_GEMM_TILE / CRA5_ATT72_NW tile overrides (same results)
     csrc = os.path.join(ROOT, "cra5_amd", "csrc")

@@ -347,7 +347,7 @@ def test_reference_written_streams_decode_or_are_refused(thin, dev, golden_dir, 
     c = np.load(f"{golden_dir}/thin_cands.npz")
     eb, gc = thin.entropy_bottleneck, thin.gaussian_conditional
     z_idx = eb._build_indexes((1, eb.channels, 18, 36))
-    decoded = refused = desync = 0
+    decoded = refused = desync = benign = 0
     for k, seed in enumerate(c["seeds"]):
         z_ref = c["z_sym"][k].astype(np.int32)
         idx_ref, sym_ref = c["idx_full"][k].astype(np.int32), c["sym_full"][k].astype(np.int32)
@@ -358,21 +358,26 @@ def test_reference_written_streams_decode_or_are_refused(thin, dev, golden_dir, 
         idx_own = ops.gaussian_conditional(sc, mu, gc.scale_table, sym_in=torch.zeros_like(mu, dtype=torch.int32),
                                            want=("idx",), scale_bound=thin._scale_bound())["idx"].cpu().numpy().reshape(-1)
         agree = np.array_equal(idx_own, idx_ref)
-        if agree:
+        try:
             y_hat = thin.decompress([[y_str], [z_str]], (18, 36), return_format='latent')
-            sym = torch.round(y_hat[0].reshape(-1) - mu.reshape(-1)).int().cpu().numpy()
-            assert np.array_equal(sym, sym_ref), f"seed {seed}: indexes agree but the decoded symbols differ"
-            decoded += 1
-        else:
-            with pytest.raises(Cra5Error) as ei:
-                thin.decompress([[y_str], [z_str]], (18, 36), return_format='latent')
+        except Cra5Error as e:
+            assert not agree, f"seed {seed}: every CDF index agrees with the encoder's, yet the stream was refused: {e}"
             refused += 1
-            desync += isinstance(ei.value, StreamDesyncError)
-    print(f"{len(c['seeds'])} reference-written thin frames: {decoded} decode to the reference's symbols, {refused} refused "
-          f"({desync} by the end-state check, {refused - desync} by a stream error on the way)")
-    assert decoded + refused == len(c["seeds"]) and decoded >= 12 and refused >= 6     # round 5 probe: 20 / 16 by index
+            desync += isinstance(e, StreamDesyncError)
+            continue
+        # it decoded: then it decoded the REFERENCE's symbols, all of them - never a frame read past a foreign index.  (A
+        # foreign index can be harmless: neighbouring table rows share the (start, range) of bins in their tails; the
+        # coder then stays in step and the end-state check passes - that is a correct decode, not a missed one.)
+        sym = torch.round(y_hat[0].reshape(-1) - mu.reshape(-1)).int().cpu().numpy()
+        assert np.array_equal(sym, sym_ref), f"seed {seed}: decoded without an error but not to the reference's symbols"
+        decoded += 1
+        benign += not agree
+    print(f"{len(c['seeds'])} reference-written thin frames: {decoded} decode to the reference's symbols ({benign} of them "
+          f"across a harmless foreign index), {refused} refused ({desync} by the end-state check, {refused - desync} by a "
+          "stream error on the way)")
+    assert decoded + refused == len(c["seeds"]) and decoded >= 12 and refused >= 6     # round 5 probe: 20 agree on every index
     ledger.ran("36 reference-written thin frames: decode exactly or are refused, never garbage",
-               f"{decoded} decoded, {refused} refused ({desync} CRA5_ERR_DESYNC)")
+               f"{decoded} decoded ({benign} across a harmless foreign index), {refused} refused ({desync} CRA5_ERR_DESYNC)")
 
 
 def test_thin_vs_cpu_oracle(thin, thin_side, dev):
@@ -1201,3 +1206,46 @@ def test_compact_records_same_streams_and_reconstruction_incl_the_32_bit_fallbac
     assert out_b["strings"] == out_b32["strings"] and torch.equal(y_hat, y_hat32)
     assert abs(float(y_hat[0, 3, 10, 20] - y_big[0, 3, 10, 20])) <= 0.5 + 1e-3
     assert abs(float(y_hat[0, 5, 11, 21] - y_big[0, 5, 11, 21])) <= 0.5 + 1e-3
+
+
+def test_hyper_prior_graphs_are_bit_identical(thin, dev):
+    """Round 6: h_a / h_s run as per-thread replayed hipGraphs (one launch per side instead of ~33; VAEformer._graphed).  The
+    graph holds the SAME kernels in the same order on the same buffers: z, mu, sigma, every CDF index and symbol equal the
+    eager launches bit for bit - on the call that captures and on replays with NEW inputs - and an in-place update of a
+    hyper-prior weight re-captures instead of replaying stale derived weights."""
+    frames = [synth.synth_frame(8, seed=300 + i).unsqueeze(0).to(dev) for i in range(4)]
+    ys = [thin.encode_latent(x, type='float')[0][0].contiguous() for x in frames]
+
+    def side(y):
+        s = thin._latent_side_frame(y)
+        torch.cuda.synchronize()
+        return {k: s[k].clone() for k in ("z", "z_sym", "scales", "means", "idx", "y_sym")}
+    prev = thin.hyper_graphs
+    try:
+        thin.hyper_graphs = False
+        eager = [side(y) for y in ys]
+        thin.hyper_graphs = True
+        thin._tls.graphs = {}
+        got = [side(y) for y in ys]          # call 0 eager, call 1 captures + replays, calls 2-3 replay
+        assert thin._tls.graphs["h_a"]["graph"] is not None and thin._tls.graphs["h_s"]["graph"] is not None
+        for a, b in zip(eager, got):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        # an in-place weight update: the next call must not replay the old graph (its derived split weights are stale)
+        w = thin.h_s.blocks[0].mlp.fc1.weight
+        w0 = w.detach().clone()
+        with torch.no_grad():
+            w.mul_(1.5)
+        thin.hyper_graphs = False
+        e2 = side(ys[0])
+        thin.hyper_graphs = True
+        g2 = [side(ys[0]) for _ in range(3)]
+        assert not torch.equal(e2["means"], eager[0]["means"])
+        for g in g2:
+            assert torch.equal(g["means"], e2["means"]) and torch.equal(g["idx"], e2["idx"])
+    finally:
+        thin.hyper_graphs = prev
+        thin._tls.graphs = {}
+        if "w0" in locals():
+            with torch.no_grad():
+                w.copy_(w0)              # (the module-scoped model goes back to the fixture's weights, bit for bit)
