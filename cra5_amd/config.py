@@ -36,7 +36,6 @@ class RuntimeConfig:
     gpu_slots: int = 3               # frames inside a GPU phase at a time when phases overlap (0 = unlimited)
     inflight: int = 12               # frames in flight per GPU (bench.py, batch API default)
     switch_interval_s: float = 0.0002   # CPython GIL hand-over interval while frame threads run (0 = leave it)
-    hyper_graphs: bool = True        # the hyper-prior phases (h_a, h_s: ~33 launch-bound kernels each) as replayed hipGraphs
     # ---- host link --------------------------------------------------------------------------------------------------
     copy_threads: int = 8            # host threads of ONE staged single-frame copy (cra5_copy_*_staged)
     batch_copy_threads: int = 1      # ... per frame of the batch API (1: one numpy copy on the frame thread)
@@ -48,7 +47,7 @@ class RuntimeConfig:
     ENV = {   # field -> environment variable (the ONLY place these names are read)
         "precision": "CRA5_PRECISION", "gemm_engine": "CRA5_GEMM", "attn_engine": "CRA5_ATTN", "range_guard": "CRA5_RANGE_GUARD",
         "gpu_exclusive": "CRA5_GPU_EXCLUSIVE", "gpu_slots": "CRA5_GPU_SLOTS", "inflight": "CRA5_INFLIGHT",
-        "switch_interval_s": "CRA5_SWITCH_INTERVAL", "hyper_graphs": "CRA5_HYPER_GRAPHS", "copy_threads": "CRA5_COPY_THREADS",
+        "switch_interval_s": "CRA5_SWITCH_INTERVAL", "copy_threads": "CRA5_COPY_THREADS",
         "batch_copy_threads": "CRA5_BATCH_COPY_THREADS", "link_serial": "CRA5_LINK_SERIAL",
         "numa_bind_single": "CRA5_NUMA_BIND_SINGLE", "weights": "CRA5_WEIGHTS",
     }

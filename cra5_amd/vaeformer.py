@@ -330,7 +330,6 @@ class VAEformer(nn.Module):
         # keeps a kernel's tail filled by another frame's blocks without letting ALL frames fall
         # into the host (rANS) phase together, which idles the GPU.  0 = unlimited.
         self.gpu_slots = rc.gpu_slots
-        self.hyper_graphs = rc.hyper_graphs     # h_a / h_s as replayed hipGraphs (one launch per side; see _graphed)
         # Bit-identical implementation alternatives, kept because tests compare the two forms (attributes, no environment
         # variable): y symbols resolved against the CDF tables by a device kernel (same byte stream) | on the host;
         # decode side: uint8 CDF indexes / int16 symbols between device and host coder | the int32 records of the
@@ -734,65 +733,7 @@ class VAEformer(nn.Module):
                           out_name=f"hy_hid{d}")
         self._hy_mm(hid, pre + ".mlp.fc2", blk.mlp.fc2.weight, bias=blk.mlp.fc2.bias, res=t, out=t)
 
-    # ---- hyper-prior phases as replayed hipGraphs (round 6) --------------------------------------------------------
-    # h_a and h_s are ~33 launches each of 5-20 us kernels on 648 tokens x 360: launch-bound on the device (0.43 + 0.44 ms)
-    # and 0.3 ms of Python each on the host thread that holds the GIL.  Per host thread the launch sequence of a phase is
-    # captured ONCE into a hipGraph (thread-local capture on a side stream: other frame threads keep launching) and
-    # replayed afterwards: one launch per side, the same kernels in the same order on the same per-thread buffers - bit
-    # for bit the eager results (tests/test_model_gpu.py::test_hyper_prior_graphs_are_bit_identical).  A graph is tied
-    # to the input shape and to the hyper-prior parameters' versions (an in-place weight update re-captures); bench.py's
-    # per-launch kernel timer and an ongoing capture fall back to eager launches.
-    def _hyper_epoch(self):
-        ps = self.__dict__.get("_hyper_params")
-        if ps is None:
-            ps = self.__dict__["_hyper_params"] = [q for n, q in self.named_parameters() if n.startswith(("h_a.", "h_s."))]
-        v = 0
-        for q in ps:
-            v += q._version
-        return (v, ps[0].data_ptr() if ps else 0)
-
-    def _graphed(self, name, fn, x):
-        if not self.hyper_graphs or ops.TIMER is not None or torch.cuda.is_current_stream_capturing():
-            return fn(x)
-        gs = getattr(self._tls, "graphs", None)
-        if gs is None:
-            gs = self._tls.graphs = {}
-        key = (tuple(x.shape), self._hyper_epoch())
-        st = gs.get(name)
-        if st is None or st["key"] != key:
-            # first call under this key: eager (builds this thread's workspaces and the derived weights, whose first
-            # build synchronises - not capturable); the next call captures
-            gs[name] = {"key": key, "graph": None}
-            return fn(x)
-        if st["graph"] is None:
-            cur = torch.cuda.current_stream()
-            side = getattr(self._tls, "capture_stream", None)
-            if side is None:
-                side = self._tls.capture_stream = torch.cuda.Stream(device=self.device)
-            st["x"] = torch.empty_like(x)
-            st["x"].copy_(x)
-            side.wait_stream(cur)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side), ops.stream_scope():
-                g.capture_begin(capture_error_mode="thread_local")
-                try:
-                    st["out"] = fn(st["x"])
-                finally:
-                    g.capture_end()
-            cur.wait_stream(side)
-            st["graph"] = g
-        elif st["x"].data_ptr() != x.data_ptr():
-            st["x"].copy_(x)
-        st["graph"].replay()           # (on torch's current stream: the frame's, or the high-priority h_s stream)
-        return st["out"]
-
     def _h_a_frame(self, y):
-        return self._graphed("h_a", self._h_a_frame_eager, y.contiguous())
-
-    def _h_s_frame(self, z_hat):
-        return self._graphed("h_s", self._h_s_frame_eager, z_hat.contiguous())
-
-    def _h_a_frame_eager(self, y):
         """y [L, Hp, Wp] -> z [Cz, Hz*Wz] (vit_nlc.py:488-551)."""
         cfg = self.cfg
         d = cfg['h_embed_dim']
@@ -811,7 +752,7 @@ class VAEformer(nn.Module):
         ztok = self._hy_mm(u, "h_a.quan_mlp.fc2", m.fc2.weight, bias=m.fc2.bias)
         return ops.transpose(ztok)  # [Cz, n]
 
-    def _h_s_frame_eager(self, z_hat):
+    def _h_s_frame(self, z_hat):
         """z_hat [Cz, n] -> (scales, means), each [L, Hp, Wp] (vit_nlc.py:696-748, 665-680;
         chunk order vaeformer.py:369).  Deterministic: same kernels / reduction order on the
         encode and the decode side."""
