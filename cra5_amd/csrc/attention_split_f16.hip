@@ -441,8 +441,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
     DST = acc_;                                                                           \
   }
   // D = A.B + C with C a DIFFERENT, persistent register tuple (the -m_run vector): as a builtin hipcc ties D to C and
-  // copies the 16 registers in front of every tile.  s_nop: C is written by VALU in the (rare) rescale branch, and no
-  // hazard wait states are inserted for inline asm; the K fragment's s_waitcnt is (operands of the asm statement).
+  // copies the 16 registers in front of every tile.  C is written by an MFMA in the (rare) shift path, which pads the wait
+  // states this asm statement does not get from the hazard recogniser (see shift()); the K fragment's s_waitcnt is (operands
+  // of the asm statement).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CRA5_MFMA_FROM(D, A, B, C) \
   asm("s_nop 3\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(D) : "v"(A), "v"(B), "v"(C))
@@ -659,6 +660,13 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 ? 1 : (NW == 4 ? 3 : 2))) void wi
       s_cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bd, s_cur, 0, 0, 0);
       negm = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bd, negm, 0, 0, 0);
       if (also) *also = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, bd, *also, 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+      // negm is the SrcC of the next tile's first score MFMA, which is INLINE ASM (CRA5_MFMA_FROM): no hazard wait states
+      // are inserted for it, and an XDL write followed by an overlapped SrcC read of another MFMA needs the writer's passes
+      // + 2 (16-pass MFMA: 18).  Spend them here, in the rare shift path, instead of relying on the K-fragment reads that
+      // happen to sit in between.
+      asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#endif
     };
     if (HI) {
       // the first tile of a segment sets the reference (either direction) from its max, known from the prologue; later

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(WM *WN * 64, ((STAGES == 1 || (WM * WN == 4 && TM =
   // launcher refuses pitches of 2^21 k-columns (2^22 halves) and more, far above anything the path has).
   constexpr bool ASM_DMA = ((TM == 4 || TM == 3) && NPROD >= 2 && WM == 2 && WN == 4 && !LONGK);
   static_assert(!ASM_DMA || BM % (WM * WN * 8) == 0, "A / W staging instructions must not straddle");
+  // the generic staging path below advances a source by 2 * KSTEP halves per k-step, which is right for split rows only:
+  // plain-row operands (NPROD == 2) exist with the hand-written DMA's kstride_a / kstride_w alone
+  static_assert(NPROD != 2 || ASM_DMA, "the wide reduced-precision form needs the ASM_DMA staging (plain-row k-stride)");
   unsigned soff[IPW];
   unsigned long long curA = 0, curW = 0;
   // NPROD == 3: one instruction = 8 rows x 128 B: a row's [32 hi | 32 lo] chunk is one cache line, requested

@@ -329,7 +329,7 @@ def test_attention_split_softmax_spike(dev, boost):
 @pytest.mark.parametrize("case", ["boost4", "boost0.5", "boost1", "low_start", "ramp"])
 def test_attention_hi_only_reference_point(dev, case):
     """Reduced-precision attention (hi_only): the exponent's reference point lives in the score MFMA's C operand
-    (p = exp2(acc) with Q pre-scaled by scale * log2 e) and is moved by an MFMA when a tile's max is 2^8 above it.
+    (p = exp2(acc) with Q pre-scaled by scale * log2 e) and is moved by an MFMA when a tile's row sum shows that some p left 2^13 (P_SAFE; the fp32-accurate form defers at 2^8).
     Late dominant keys (as the fp32-accurate twin above), a first tile far BELOW zero (the first tile sets the
     reference in either direction) and a steady ramp (many small moves) against float64 on the f16-rounded operands."""
     H, W, C, heads = 8, 72, 64, 1

@@ -24,4 +24,9 @@ python tools/traffic_summary.py $O $O/$T
 rm -rf $O/prof_default $O/prof_excl
 for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/pmc_traffic_$c; done
 cut -c1-200 $O/${T}_bench_default.json; cut -c1-200 $O/${T}_bench_exclusive.json
-python tools/kstats.py $O/${T}_bench_exclusive_kernel_stats.csv 16
+python - "$O/${T}_bench_exclusive_kernel_stats.csv" <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: -float(r["TotalDurationNs"]))[:16]
+for r in rows:
+    print(f"{float(r['TotalDurationNs']) / 1e6:9.2f} ms  {int(float(r['Calls'])):6d} x {float(r['TotalDurationNs']) / float(r['Calls']) / 1e3:8.1f} us  {r['Name'][:100]}")
+PY
