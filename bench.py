@@ -1155,9 +1155,19 @@ def main():
                 budget = single_frame_budget(api, host)
             except Exception as ex:  # noqa: BLE001
                 budget = {"error": repr(ex)}
+            # the same call pair under the entropy-matched weight variant (a trained model's stream sizes: the serial rANS
+            # phases are what differs - cra5_amd/synth.py)
+            matched_budget = None
+            try:
+                synth.apply_variant(net, seed=7, variant="matched")
+                matched_budget = single_frame_budget(api, host)
+            except Exception as ex:  # noqa: BLE001
+                matched_budget = {"error": repr(ex)}
+            finally:
+                synth.apply_variant(net, seed=7, variant="default")
             result["api_single_frame"] = {
                 "value": 1.0 / (e + d), "unit": "frames/s", "encode_s": e, "decode_s": d, "threads": 1,
-                "budget_ms": budget,
+                "budget_ms": budget, "entropy_matched_weights": matched_budget,
                 "what": "cra5_api.encode_era5_as_bin(data=host fp32 array) + decode_from_bin('de_normalized'), serial, "
                         "H2D of the 1.11 GB frame and .bin write / read included, x_hat left on the device as the "
                         "reference does (tools/api_testpy_loop.py times every call of the reference's test.py loop)"}

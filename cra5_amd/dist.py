@@ -392,6 +392,7 @@ def plan_inflight(reports, requested, pool_frames):
     """Frames in flight for EVERY rank of the job (one figure: the ranks step in lock-step through barriers) from the
     gathered reports.  Pure function (tested on CPU).  Returns (inflight, [reasons])."""
     inflight, why = int(requested), []
+    floor = min(MIN_INFLIGHT, inflight)        # (a caller that ASKS for one frame in flight - profiling passes - gets it)
     for r in reports:
         free = r.get("free_bytes")
         if free is not None:
@@ -405,8 +406,8 @@ def plan_inflight(reports, requested, pool_frames):
         if ncpu is not None and ncpu < inflight:
             why.append(f"rank {r['rank']}: {ncpu} host CPUs in its mask < {inflight} frame threads (each frame's rANS phase "
                        "wants a core of its own)")
-            inflight = max(MIN_INFLIGHT, min(inflight, ncpu))     # (few cores slow the job down, they do not stop it)
-    if inflight < MIN_INFLIGHT:
+            inflight = max(floor, min(inflight, ncpu))     # (few cores slow the job down, they do not stop it)
+    if inflight < floor:
         raise RuntimeError("preflight: the job cannot keep even %d frames in flight: %s" % (MIN_INFLIGHT, "; ".join(why)))
     return inflight, why
 

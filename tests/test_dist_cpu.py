@@ -240,6 +240,7 @@ def test_plan_inflight_pure():
     few[6]["n_cpus"] = 5                              # a cgroup that leaves rank 6 five CPUs
     n, why = D.plan_inflight(few, 12, 8)
     assert n == 5 and "rank 6" in why[0]
+    assert D.plan_inflight(ok, 1, 1) == (1, [])       # one frame in flight on request (profiling passes): not a failure
     none = [dict(rank=0, free_bytes=None, n_cpus=None)]          # CPU dry run: nothing to check
     assert D.plan_inflight(none, 12, 8) == (12, [])
     import pytest

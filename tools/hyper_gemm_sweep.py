@@ -1,6 +1,6 @@
 """Kernel durations of the small-M GEMM instantiations per hyper-prior shape.  Run under rocprofv3:
    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -o hy -- python tools/hyper_gemm_sweep.py <TN> <KS>
-(one process per instantiation: the override is read once), then tools/kstats.py /tmp/p."""
+(one process per instantiation: the override is read once), then the per-kernel averages of /tmp/p."""
 import os
 import sys
 

@@ -48,4 +48,3 @@ cd $R
 python tools/traffic_summary.py $F $O/${T}_f16 "--precision f16" | tail -8
 rm -rf $F
 cut -c1-160 $O/${T}_f16_bench_exclusive.json
-python tools/kstats.py $O/${T}_f16_bench_exclusive_kernel_stats.csv 14
