@@ -74,19 +74,72 @@ inline Resolved resolve(const Tables &t, int32_t sym, int32_t ci) {
   return r;
 }
 
+// Division by a bin's frequency as a multiplication (round 6).  Rans64EncPut computes x / freq and x % freq with a 64-bit
+// divide on the coder's serial dependency chain (~20 cycles of the ~28 a symbol takes); the published rans64 encoder
+// (Rans64EncSymbolInit / Rans64EncPutSymbol) replaces it by a multiplication with a pre-computed reciprocal - Alverson,
+// "Integer division using reciprocals": q = mulhi(x, rcp) >> shift is EXACTLY floor(x / freq) for every state the coder
+// can be in (x < 2^47 freq) - and folds the remainder into x + bias + q (2^16 - freq).  The resolved encoders get
+// (start, freq) per symbol from the device, so the reciprocals live in one table over all 65 536 frequencies (1 MB, built
+// once, thread-safe; a frame touches a few hundred of its lines).  Same states, same words, same streams.
+struct Rcp {
+  uint64_t rcp;
+  uint32_t shift;
+  uint32_t pad;
+};
+const Rcp *rcp_table() {
+  static const std::vector<Rcp> tab = [] {
+    std::vector<Rcp> t(65537);
+    t[0] = Rcp{0, 0, 0};
+    t[1] = Rcp{~0ull, 0, 0};                      // q = mulhi(x, 2^64 - 1) = x - 1; the bias below makes up for it
+    for (uint32_t freq = 2; freq <= 65536; ++freq) {
+      uint32_t shift = 0;
+      while (freq > (1u << shift)) ++shift;
+      // ceil(2^(shift + 63) / freq) by long division in two 32-bit steps
+      uint64_t x0 = freq - 1;
+      const uint64_t x1 = 1ull << (shift + 31);
+      const uint64_t t1 = x1 / freq;
+      x0 += (x1 % freq) << 32;
+      const uint64_t t0 = x0 / freq;
+      t[freq] = Rcp{t0 + (t1 << 32), shift - 1, 0};
+    }
+    return t;
+  }();
+  return tab.data();
+}
+inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+  return static_cast<uint64_t>((static_cast<unsigned __int128>(a) * b) >> 64);
+}
+
 struct Encoder {
   uint64_t x = kRansL;
   uint32_t *ptr;
+  const Rcp *rcp = rcp_table();
   inline void put(uint32_t start, uint32_t freq) {
-    // Rans64EncPut.  The renormalisation is taken for ~40 % of the symbols of a 13-bit/symbol
-    // stream - unpredictable as a branch - so the word is always written below the cursor and the
-    // cursor / state move by select.
+    // Rans64EncPutSymbol.  The renormalisation is taken for ~40 % of the symbols of a 13-bit/symbol stream.
     const uint64_t x_max = ((kRansL >> kProbBits) << 32) * freq;
     if (x >= x_max) {
       *--ptr = static_cast<uint32_t>(x);
       x >>= 32;
     }
-    x = ((x / freq) << kProbBits) + (x % freq) + start;
+    const Rcp r = rcp[freq];
+    const uint64_t q = mulhi64(x, r.rcp) >> r.shift;
+    // x / freq * 2^16 + x % freq + start  ==  x + start + q (2^16 - freq); freq = 1: q = x - 1 -> + (2^16 - 1)
+    x = x + start + (freq < 2 ? ((1u << kProbBits) - 1) : 0u) + q * ((1u << kProbBits) - freq);
+  }
+  // `total` (1..8) bypass nibbles at once - bits = nibble_first << 4 (total - 1) | ... | nibble_last, pushed first to
+  // last: what `total` calls of put_bits() do, with the ONE renormalisation they can take (x >= 2^59 before a nibble;
+  // after it the state is below 2^31 and seven more nibbles fit) placed where they would take it.
+  inline void put_nibbles(uint32_t bits, int total) {
+    const int msb = 63 - __builtin_clzll(x);
+    int first = (62 - msb) >> 2;                  // nibbles that go in before x reaches 2^59
+    if (first > total) first = total;
+    const int rest = total - first;
+    x = (x << (4 * first)) | (bits >> (4 * rest));
+    if (rest) {
+      *--ptr = static_cast<uint32_t>(x);
+      x >>= 32;
+      x = (x << (4 * rest)) | (bits & ((1u << (4 * rest)) - 1));
+    }
   }
   inline void put_bits(uint32_t val) {  // 4-bit bypass symbol
     constexpr uint32_t freq = 1u << (16 - kBypassBits);
@@ -182,33 +235,48 @@ struct Decoder {
   }
 };
 
-// Bin lookup for the decoder.  The reference scans the CDF row linearly (rans_interface.cpp:246-250),
-// a binary search is ~6 unpredictable branches per symbol; here every row gets, on first use, a small
-// table from the top bits of the cumulative frequency to the bin holding the first value of that
-// bucket, and the scan from there is 0-1 steps for the distributions this coder sees.  The table is a
-// pure function of the row, so the decoded symbols are identical to the linear scan's.
-// Measured on a real frame of the synthetic-weight model (tools/rans_bench.py, EPYC 9575F): decode
-// 44.7 -> 37.8 ms, 2.5x on low-entropy streams; branch-free renormalisation on either side: no change
-// (52 % of that frame's symbols sit in the narrowest row and escape - the serial state chain rules).
-struct RowLut {
-  std::vector<uint16_t> first;   // bucket -> bin of (bucket << shift)
-  int shift = 0;
+// Bin lookup for the decoder.  The reference scans the CDF row linearly (rans_interface.cpp:246-250), a binary search is
+// ~6 unpredictable branches per symbol.  Every row gets, on first use, a table from the top bits of the cumulative
+// frequency to a PACKED entry (round 6; rounds 2-5: the bin index alone, followed by loads of cdf[s + 1], cdf[s] on the
+// coder's serial chain): bin | start << 16 | freq << 32, flagged EXACT when the whole bucket lies inside that bin - then
+// the one 8-byte load is all the state update needs (a Gaussian row's mass sits in a few wide bins: 95-99 % of the
+// symbols); otherwise the entry names the bin of the bucket's first value and the scan from there is 0-2 steps.  The
+// table is a pure function of the row: the decoded symbols are the linear scan's.
+// Measured on a real frame of the synthetic-weight model and on an entropy-matched stream (EPYC-class host, one core):
+// see profiles/EXPERIMENTS.md, round 6.
+constexpr uint64_t kExact = 1ull << 63;
+constexpr int kLutBits = 10;               // 1024 buckets of 64 cumulative values: 8 KB per row in use (12 bits: the hot rows
+                                           // of a frame fall out of L1 / L2 - measured slower on both test streams)
+struct RowDec {
+  const uint64_t *tab = nullptr;           // nullptr: malformed row -> generic search
+  const int32_t *cdf = nullptr;
+  int32_t csz = 0, max_value = 0, offset = 0;
   bool built = false;
 };
 
-static void build_row_lut(RowLut &l, const int32_t *cdf, int32_t csz) {
-  // buckets ~ 8x the number of bins, between 2^6 and 2^12 (16 cumulative values per bucket at most)
-  int bits = 6;
-  while (bits < 12 && (1 << bits) < 8 * csz) ++bits;
-  l.shift = kProbBits - bits;
-  l.first.assign(static_cast<size_t>(1) << bits, 0);
+static void build_row_dec(RowDec &r, std::vector<uint64_t> &store, const int32_t *cdf, int32_t csz, int32_t offset) {
+  r.cdf = cdf;
+  r.csz = csz;
+  r.max_value = csz - 2;
+  r.offset = offset;
+  r.built = true;
+  // a well-formed row is non-decreasing, starts at 0, ends within 2^16 and fits uint16 bins; anything else goes through
+  // the generic search
+  bool ok = csz <= 65535 && cdf[0] == 0 && cdf[csz - 1] <= (1 << kProbBits);
+  for (int32_t k = 1; ok && k < csz; ++k) ok = cdf[k] >= cdf[k - 1];
+  if (!ok) return;
+  constexpr int shift = kProbBits - kLutBits;
+  store.assign(static_cast<size_t>(1) << kLutBits, 0);
   int32_t s = 0;
-  for (int32_t b = 0; b < (1 << bits); ++b) {
-    const int32_t cum = b << l.shift;
-    while (s + 1 < csz && cdf[s + 1] <= cum) ++s;   // largest s with cdf[s] <= cum (cdf[0] = 0)
-    l.first[static_cast<size_t>(b)] = static_cast<uint16_t>(s);
+  for (int32_t b = 0; b < (1 << kLutBits); ++b) {
+    const int32_t lo = b << shift, hi = lo + (1 << shift) - 1;
+    while (s + 1 < csz && cdf[s + 1] <= lo) ++s;   // largest s with cdf[s] <= lo (cdf[0] = 0)
+    uint64_t e = static_cast<uint64_t>(s);
+    if (s <= r.max_value && cdf[s + 1] > hi)       // the bucket lies inside bin s (a real bin: s + 1 < csz)
+      e |= kExact | (static_cast<uint64_t>(cdf[s]) << 16) | (static_cast<uint64_t>(cdf[s + 1] - cdf[s]) << 32);
+    store[static_cast<size_t>(b)] = e;
   }
-  l.built = true;
+  r.tab = store.data();
 }
 
 // IdxT / OutT: int32_t / int32_t is the reference's interface; uint8_t / int16_t the compact records of the frame path
@@ -217,42 +285,45 @@ static void build_row_lut(RowLut &l, const int32_t *cdf, int32_t csz) {
 template <class IdxT, class OutT>
 int decode_symbols(Decoder &d, const IdxT *indexes, size_t n, const Tables &t, OutT *out) {
   constexpr uint64_t mask = (1ull << kProbBits) - 1;
-  std::vector<RowLut> luts(static_cast<size_t>(t.n_cdfs > 0 ? t.n_cdfs : 0));
+  constexpr int shift = kProbBits - kLutBits;
+  const size_t n_rows = static_cast<size_t>(t.n_cdfs > 0 ? t.n_cdfs : 0);
+  std::vector<RowDec> rows(n_rows);
+  std::vector<std::vector<uint64_t>> store(n_rows);
   for (size_t i = 0; i < n; ++i) {
     const int32_t ci = static_cast<int32_t>(indexes[i]);
-    if (ci < 0 || ci >= t.n_cdfs || t.sizes[ci] < 2 || t.sizes[ci] > t.stride) return CRA5_ERR_INDEX;
-    const int32_t *cdf = t.cdfs + static_cast<size_t>(ci) * t.stride;
-    const int32_t csz = t.sizes[ci];
-    const int32_t max_value = csz - 2;
+    if (ci < 0 || ci >= t.n_cdfs) return CRA5_ERR_INDEX;
+    RowDec &r = rows[static_cast<size_t>(ci)];
+    if (!r.built) {
+      if (t.sizes[ci] < 2 || t.sizes[ci] > t.stride) return CRA5_ERR_INDEX;
+      build_row_dec(r, store[static_cast<size_t>(ci)], t.cdfs + static_cast<size_t>(ci) * t.stride, t.sizes[ci], t.offsets[ci]);
+    }
     const int32_t cum = static_cast<int32_t>(d.x & mask);
-    RowLut &l = luts[static_cast<size_t>(ci)];
-    if (!l.built) {
-      // a well-formed row is non-decreasing, starts at 0 and fits uint16 bins; anything else goes
-      // through the generic search below
-      bool ok = csz <= 65535 && cdf[0] == 0;
-      for (int32_t k = 1; ok && k < csz; ++k) ok = cdf[k] >= cdf[k - 1];
-      if (ok) build_row_lut(l, cdf, csz);
-      else l.built = true, l.shift = -1;
-    }
     int32_t s;
-    if (l.shift >= 0) {
-      s = l.first[static_cast<size_t>(cum >> l.shift)];
-      // first entry > cum, minus one: usually 0-1 steps from the bucket's bin; the first two are
-      // taken by arithmetic (a data-dependent trip count mispredicts), the loop mops up tails
-      s += (s + 1 < csz && cdf[s + 1] <= cum) ? 1 : 0;
-      s += (s + 1 < csz && cdf[s + 1] <= cum) ? 1 : 0;
-      while (s + 1 < csz && cdf[s + 1] <= cum) ++s;
-      if (cdf[csz - 1] <= cum) s = csz - 1;            // cum beyond the row's total: rejected below
+    uint32_t start, freq;
+    const uint64_t e = r.tab ? r.tab[cum >> shift] : 0;
+    if (e & kExact) {
+      s = static_cast<int32_t>(e & 0xFFFFu);
+      start = static_cast<uint32_t>(e >> 16) & 0xFFFFu;
+      freq = static_cast<uint32_t>(e >> 32) & 0x1FFFFu;
     } else {
-      s = static_cast<int32_t>(std::upper_bound(cdf, cdf + csz, cum) - cdf) - 1;
+      const int32_t *cdf = r.cdf;
+      const int32_t csz = r.csz;
+      if (r.tab) {
+        s = static_cast<int32_t>(e & 0xFFFFu);
+        // first entry > cum, minus one: 0-2 steps from the bucket's bin
+        while (s + 1 < csz && cdf[s + 1] <= cum) ++s;
+        if (cdf[csz - 1] <= cum) s = csz - 1;            // cum beyond the row's total: rejected below
+      } else {
+        s = static_cast<int32_t>(std::upper_bound(cdf, cdf + csz, cum) - cdf) - 1;
+      }
+      if (s < 0 || s > r.max_value) return CRA5_ERR_STREAM;
+      start = static_cast<uint32_t>(cdf[s]);
+      freq = static_cast<uint32_t>(cdf[s + 1] - cdf[s]);
     }
-    if (s < 0 || s > max_value) return CRA5_ERR_STREAM;
-    const uint32_t start = static_cast<uint32_t>(cdf[s]);
-    const uint32_t freq = static_cast<uint32_t>(cdf[s + 1] - cdf[s]);
-    d.x = freq * (d.x >> kProbBits) + (d.x & mask) - start;
+    d.x = freq * (d.x >> kProbBits) + static_cast<uint64_t>(cum) - start;
     if (d.x < kRansL) d.x = (d.x << 32) | d.word();
     int32_t value = s;
-    if (value == max_value) {
+    if (value == r.max_value) {
       uint32_t val = d.get_bits();
       int32_t n_bypass = static_cast<int32_t>(val);
       while (val == kBypassMax && d.ok) {
@@ -264,10 +335,10 @@ int decode_symbols(Decoder &d, const IdxT *indexes, size_t n, const Tables &t, O
       for (int j = 0; j < n_bypass; ++j) raw |= d.get_bits() << (j * kBypassBits);
       value = static_cast<int32_t>(raw >> 1);
       if (raw & 1u) value = -value - 1;
-      else value += max_value;
+      else value += r.max_value;
     }
     if (!d.ok) return CRA5_ERR_STREAM;
-    const int32_t sym = value + t.offsets[ci];
+    const int32_t sym = value + r.offset;
     if (sizeof(OutT) < sizeof(int32_t) && (sym < -32768 || sym > 32767)) return CRA5_ERR_RANGE;
     out[i] = static_cast<OutT>(sym);
   }
@@ -370,8 +441,8 @@ int cra5_rans_encode_resolved_compact(const uint32_t *start_range, const uint16_
         std::free(buf);
         return CRA5_ERR_INDEX;
       }
-      for (int j = n_nibbles - 1; j >= 0; --j) e.put_bits((r >> (j * kBypassBits)) & kBypassMax);
-      e.put_bits(static_cast<uint32_t>(n_nibbles));
+      // payload nibbles most significant first, then the count nibble: one shifted word (<= 4 nibbles)
+      e.put_nibbles((r << kBypassBits) | static_cast<uint32_t>(n_nibbles), n_nibbles + 1);
     }
     const uint32_t freq = sr >> 16;
     if (!freq) {

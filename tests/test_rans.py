@@ -504,3 +504,40 @@ def test_reference_decoder_semantics_are_silent_garbage():
         caught_by_end_state += isinstance(ei.value, StreamDesyncError)
     print(f"{cases} one-index flips: reference semantics silent garbage {silent}, product end-state check {caught_by_end_state}")
     assert silent >= cases // 2 and caught_by_end_state >= cases // 4     # (the others run out of words: CRA5_ERR_STREAM)
+
+
+def test_encoder_reciprocal_division_is_exact_for_every_frequency():
+    """Round 6: the encoder divides by a bin's frequency with a pre-computed reciprocal (mulhi + shift, the published
+    rans64 Rans64EncPutSymbol form) instead of a 64-bit divide.  Every frequency 1 .. 65535 and its complement, as the two
+    bins of a two-bin row, over states that wander through the coder's whole range: the product's stream equals the
+    oracle's (plain `/` and `%`) byte for byte, through the one-shot encoder and through the resolved encoder; and it
+    decodes."""
+    rng = np.random.default_rng(21)
+    freqs = np.arange(1, 65536, dtype=np.int32)
+    cdf = np.zeros((freqs.size, 4), np.int32)
+    cdf[:, 1] = freqs
+    cdf[:, 2] = 65536
+    lens = np.full(freqs.size, 3, np.int32)          # two bins: symbol 0 (freq f), symbol 1 = the escape bin (65536 - f)
+    offs = np.zeros(freqs.size, np.int32)
+    idx = np.repeat(np.arange(freqs.size, dtype=np.int32), 6)
+    rng.shuffle(idx)
+    sym = np.zeros(idx.size, np.int32)               # bin 0 only: no escape payloads, pure put() traffic ...
+    a = ops.rans_encode(sym, idx, cdf, lens, offs)
+    assert a == cbind.rans_encode(sym, idx, cdf, lens, offs)
+    assert np.array_equal(ops.rans_decode(a, idx, cdf, lens, offs), sym)
+    sym2 = rng.integers(0, 3, size=idx.size).astype(np.int32)      # ... and with the complement bin + escape payloads mixed in
+    b = ops.rans_encode(sym2, idx, cdf, lens, offs)
+    assert b == cbind.rans_encode(sym2, idx, cdf, lens, offs)
+    assert np.array_equal(ops.rans_decode(b, idx, cdf, lens, offs), sym2)
+    # three-bin rows: frequencies 1, f, 65535 - f, so that f = 1 and the largest frequencies meet mid-range states too
+    cdf3 = np.zeros((freqs.size - 1, 5), np.int32)
+    cdf3[:, 1] = 1
+    cdf3[:, 2] = 1 + freqs[:-1]
+    cdf3[:, 3] = 65536
+    l3 = np.full(freqs.size - 1, 4, np.int32)
+    o3 = np.zeros(freqs.size - 1, np.int32)
+    i3 = rng.integers(0, freqs.size - 1, size=200000).astype(np.int32)
+    s3 = rng.integers(0, 2, size=i3.size).astype(np.int32)
+    c = ops.rans_encode(s3, i3, cdf3, l3, o3)
+    assert c == cbind.rans_encode(s3, i3, cdf3, l3, o3)
+    assert np.array_equal(ops.rans_decode(c, i3, cdf3, l3, o3), s3)
