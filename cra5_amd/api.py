@@ -250,7 +250,7 @@ class cra5_api:
         file_url = f'{save_root}/{year}/{time_stamp}.bin'
         os.makedirs(os.path.dirname(file_url), exist_ok=True)
         with Path(file_url).open("wb") as f:
-            f.write(binfmt.pack_bin(output["strings"], output["z_shape"]))
+            binfmt.write_bin(f, output["strings"], output["z_shape"])
         st4 = time.time()
         return dict(output=output, reading_time=st2 - st1, encoding_time=st3 - st2, saving_time=st4 - st3,
                     save_path=file_url)
@@ -412,7 +412,7 @@ class cra5_api:
         if write:
             os.makedirs(os.path.dirname(file_url), exist_ok=True)
             with Path(file_url).open("wb") as f:
-                f.write(binfmt.pack_bin(output["strings"], output["z_shape"]))
+                binfmt.write_bin(f, output["strings"], output["z_shape"])
         return dict(output=output, reading_time=t1 - t0, encoding_time=t2 - t1, saving_time=time.time() - t2,
                     save_path=file_url)
 

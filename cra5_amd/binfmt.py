@@ -33,6 +33,15 @@ def pack_bin(strings, z_shape):
     return b"".join(out)
 
 
+def write_bin(f, strings, z_shape):
+    """pack_bin straight into an open binary file: the 4.5 MB y stream is handed to the file once instead of being
+    copied into a joined bytes object first."""
+    f.write(struct.pack(">3I", int(z_shape[0]), int(z_shape[1]), len(strings)))
+    for s in strings:
+        f.write(struct.pack(">I", len(s[0])))
+        f.write(s[0])
+
+
 def unpack_bin(data):
     """bytes -> (strings [[y],[z]], z_shape)."""
     zh, zw, n = struct.unpack(">3I", data[:12])

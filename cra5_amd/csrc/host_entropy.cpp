@@ -321,21 +321,42 @@ int decode_symbols(Decoder &d, const IdxT *indexes, size_t n, const Tables &t, O
       freq = static_cast<uint32_t>(cdf[s + 1] - cdf[s]);
     }
     d.x = freq * (d.x >> kProbBits) + static_cast<uint64_t>(cum) - start;
-    if (d.x < kRansL) d.x = (d.x << 32) | d.word();
+    {
+      // renormalisation by select: the word below the cursor is read either way (from the last word of the stream when
+      // the cursor is at its end) and taken when the state fell below 2^31 - ~40 % of the symbols, a coin flip as a branch
+      const bool need = d.x < kRansL;
+      const bool room = d.p + 4 <= d.end;
+      uint32_t w;
+      std::memcpy(&w, room ? d.p : d.end - 4, 4);
+      d.ok = d.ok && (room || !need);
+      d.x = need ? ((d.x << 32) | w) : d.x;
+      d.p += need ? 4 : 0;
+    }
     int32_t value = s;
     if (value == r.max_value) {
-      uint32_t val = d.get_bits();
-      int32_t n_bypass = static_cast<int32_t>(val);
-      while (val == kBypassMax && d.ok) {
-        val = d.get_bits();
-        n_bypass += static_cast<int32_t>(val);
+      uint32_t raw;
+      int32_t n_bypass = static_cast<int32_t>(d.x & kBypassMax);
+      const int sh = (n_bypass + 1) * static_cast<int>(kBypassBits);
+      if (n_bypass <= 8 && (d.x >> sh) >= kRansL) {
+        // count nibble + payload in one piece: no nibble of them drops the state below 2^31, so the n + 1 get_bits() calls
+        // collapse into a mask and a shift (a variable trip count and a renormalisation branch per nibble mispredict;
+        // ~60 % of the escapes go this way)
+        raw = static_cast<uint32_t>((d.x >> kBypassBits) & ((1ull << (sh - kBypassBits)) - 1));
+        d.x >>= sh;
+      } else {
+        uint32_t val = d.get_bits();
+        n_bypass = static_cast<int32_t>(val);
+        while (val == kBypassMax && d.ok) {
+          val = d.get_bits();
+          n_bypass += static_cast<int32_t>(val);
+        }
+        if (n_bypass > 8) return CRA5_ERR_STREAM;  // a uint32 payload has at most 8 nibbles
+        raw = 0;
+        for (int j = 0; j < n_bypass; ++j) raw |= d.get_bits() << (j * kBypassBits);
       }
-      if (n_bypass > 8) return CRA5_ERR_STREAM;  // a uint32 payload has at most 8 nibbles
-      uint32_t raw = 0;
-      for (int j = 0; j < n_bypass; ++j) raw |= d.get_bits() << (j * kBypassBits);
-      value = static_cast<int32_t>(raw >> 1);
-      if (raw & 1u) value = -value - 1;
-      else value += r.max_value;
+      // raw odd: -(raw >> 1) - 1, even: (raw >> 1) + max_value - by mask, the sign bit of a payload is a coin flip
+      const int32_t neg = -static_cast<int32_t>(raw & 1u);
+      value = (static_cast<int32_t>(raw >> 1) ^ neg) + (r.max_value & ~neg);
     }
     if (!d.ok) return CRA5_ERR_STREAM;
     const int32_t sym = value + r.offset;

@@ -1009,6 +1009,20 @@ class VAEformer(nn.Module):
         return {"x_hat": torch.stack(xh), "likelihoods": {"y": torch.stack(yl), "z": torch.stack(zl)},
                 "posterior": _Posterior(torch.stack(ys))}
 
+    def _z_pool(self):
+        p = self.__dict__.get("_zpool")
+        if p is None:
+            with self._derive_lock:
+                p = self.__dict__.get("_zpool")
+                if p is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    p = self.__dict__["_zpool"] = ThreadPoolExecutor(max_workers=4, thread_name_prefix="cra5-z")
+        return p
+
+    def _encode_z(self, z_np, size):
+        eb = self.entropy_bottleneck
+        return eb.encode_symbols(z_np, eb._build_indexes(size))
+
     def _compress_frame(self, x=None, y=None, mean=None, std=None):
         """GPU phase (g_a + latent side, symbols staged to pinned host memory) followed by the
         host phase (two rANS streams).  Either x [C,H,W] or y [L,Hp,Wp]."""
@@ -1056,8 +1070,9 @@ class VAEformer(nn.Module):
         keep = {}
         z_sym, host = self._range_guard(0, gpu_side, "compress")
         t_host = time.perf_counter()
-        z_idx = self.entropy_bottleneck._build_indexes((1, z_sym.shape[0], z_sym.shape[1]))
-        z_str = self.entropy_bottleneck.encode_symbols(z_sym.numpy().reshape(-1), z_idx)
+        # the z stream is coded beside the y stream (round 6): two independent coders, the native calls release the GIL -
+        # 2 ms off the serial host phase of every frame (16.5 ms with the default synthetic weights, 8.5 entropy-matched)
+        z_job = self._z_pool().submit(self._encode_z, z_sym.numpy().reshape(-1), (1, z_sym.shape[0], z_sym.shape[1]))   # (joined below)
         if host[0] == "compact" and int(host[3][0]) != 0:
             # an escape payload beyond 12 bits (|symbol| thousands beyond its table row): this frame takes the 32-bit records
             with self._gpu_phase(light=True):
@@ -1079,6 +1094,7 @@ class VAEformer(nn.Module):
             _, ln, off = gc.host_tables()
             v = sym_np - off[idx_np]
             n_esc = int(np.count_nonzero((v < 0) | (v >= ln[idx_np] - 2)))
+        z_str = z_job.result()
         # symbols of the y stream coded through the escape path (rans_interface.cpp:120-160): the SURVEY 8(e) stats field
         self._tls.last_n_escape = n_esc
         if self.host_log is not None:
