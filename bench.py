@@ -424,8 +424,8 @@ STAGE = ["startup"]     # where main() is (the error line names it)
 
 def single_frame_budget(api, host_frame, reps=4):
     """Where the time of ONE serial call pair of the reference-named API goes (test.py:14-45 in the
-    reference): encode_era5_as_bin(host array) = H2D | G1 (finite probe, g_a) | G1b (h_a, h_s, GaussianConditional, records
-    to the host) | H1 (rANS z + y) | .bin write; decode_from_bin = .bin read | H2z (rANS z) | G2 (h_s, CDF indexes to the
+    reference): encode_era5_as_bin(host array) = H2D | G1 (finite probe, g_a, h_a, h_s, GaussianConditional, records to the
+    host) | H1 (rANS z beside y) | .bin write; decode_from_bin = .bin read | H2z (rANS z) | G2 (h_s, CDF indexes to the
     host) | H2y (rANS y) | G3 (de-quantise, g_s, probe).  Phases from VAEformer.phase_log / host_log + wall-clock stamps
     of the API calls; `other` = what the stamps do not cover (Python between the phases, stream syncs).  Median of the
     reps after the first."""
@@ -463,12 +463,12 @@ def single_frame_budget(api, host_frame, reps=4):
             g_dec = [e[3] - e[2] for e in net.phase_log]
             h_dec = dict(net.host_log)
             row = {"encode_total": t1 - t0, "h2d": stamp.get("h2d", 0.0),
-                   "g1_g_a": g_enc[0] if g_enc else 0.0, "g1b_latent_side": sum(g_enc[1:]),
+                   "g1_g_a_and_latent_side": g_enc[0] if g_enc else 0.0, "g1b_other_gpu_phases": sum(g_enc[1:]),
                    "h1_rans_encode": h_enc.get("enc", 0.0), "bin_write": enc["saving_time"],
                    "decode_total": t3 - t2, "h2z_rans_decode_z": h_dec.get("dec_z", 0.0),
                    "g2_h_s_indexes": g_dec[0] if g_dec else 0.0, "h2y_rans_decode_y": h_dec.get("dec_y", 0.0),
                    "g3_g_s": sum(g_dec[1:])}
-            row["encode_other"] = row["encode_total"] - sum(row[k] for k in ("h2d", "g1_g_a", "g1b_latent_side", "h1_rans_encode", "bin_write"))
+            row["encode_other"] = row["encode_total"] - sum(row[k] for k in ("h2d", "g1_g_a_and_latent_side", "g1b_other_gpu_phases", "h1_rans_encode", "bin_write"))
             row["decode_other"] = row["decode_total"] - sum(row[k] for k in ("h2z_rans_decode_z", "g2_h_s_indexes", "h2y_rans_decode_y", "g3_g_s"))
             rows.append(row)
     finally:

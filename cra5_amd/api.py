@@ -234,7 +234,13 @@ class cra5_api:
         with torch.no_grad():
             probe = self._finite_probe(frame)
             try:
-                y = self._encode_y(frame)
+                if return_format in ('latent', 'quantized'):
+                    y = self._encode_y(frame)
+                else:
+                    # g_a and the latent side as ONE GPU phase (what the batch path runs: the same kernels on the same
+                    # values, the same bytes - no stream sync and host round trip between the two halves)
+                    self.net._require_gpu()
+                    y_str, z_str = self.net._compress_frame(x=frame, mean=self._mean_flat, std=self._std_flat)
             except FloatingPointError:
                 self._require_finite(probe)     # a non-finite INPUT is the caller's ValueError
                 raise
@@ -244,7 +250,7 @@ class cra5_api:
             if return_format == 'quantized':
                 s = self.net._latent_side_guarded(y)
                 return s["y_hat"].reshape(y.shape).unsqueeze(0)
-            output = self.net.compress_from_latent(y.unsqueeze(0))
+            output = {"strings": [[y_str], [z_str]], "z_shape": torch.Size([self.net.Hz, self.net.Wz])}
         st3 = time.time()
         year = time_stamp.split('-')[0]
         file_url = f'{save_root}/{year}/{time_stamp}.bin'

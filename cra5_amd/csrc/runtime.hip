@@ -45,13 +45,28 @@ inline int cap_threads(int n_threads) {
   return n_threads < 1 ? 1 : n_threads;
 }
 
+// The chunks of one staged copy.  `ramp`: the first chunk is 1 MB and the sizes double up to `chunk` - the DMA engine
+// starts after 10 us of host memcpy instead of after a whole 32 MB chunk's (host -> device: 20.4 -> 19.8 ms of a 19.3 ms
+// transfer; the device -> host direction has nothing to wait for and keeps uniform chunks).
 struct Slices {
   size_t bytes, chunk;
   int threads;
-  size_t n_chunks() const { return (bytes + chunk - 1) / chunk; }
+  std::vector<size_t> start;   // n_chunks + 1 offsets
+  Slices(size_t bytes_, size_t chunk_, int threads_, bool ramp) : bytes(bytes_), chunk(chunk_), threads(threads_) {
+    size_t c = ramp ? (size_t(1) << 20 < chunk_ ? size_t(1) << 20 : chunk_) : chunk_;
+    for (size_t o = 0; o < bytes_;) {
+      start.push_back(o);
+      o += c;
+      if (c < chunk_) c = (2 * c < chunk_) ? 2 * c : chunk_;
+    }
+    start.push_back(bytes_);
+  }
+  size_t n_chunks() const { return start.size() - 1; }
+  size_t offset(size_t c) const { return start[c]; }
+  size_t length(size_t c) const { return start[c + 1] - start[c]; }
   // thread t's byte range inside chunk c (64-byte aligned cuts)
   void range(size_t c, int t, size_t &lo, size_t &hi) const {
-    const size_t c0 = c * chunk, len = (c0 + chunk <= bytes ? chunk : bytes - c0);
+    const size_t c0 = start[c], len = start[c + 1] - c0;
     const size_t per = ((len + threads - 1) / threads + 63) & ~size_t(63);
     lo = c0 + (size_t(t) * per < len ? size_t(t) * per : len);
     hi = c0 + (size_t(t + 1) * per < len ? size_t(t + 1) * per : len);
@@ -65,7 +80,7 @@ extern "C" int cra5_copy_h2d_staged(void *dst_dev, const void *src_host, void *p
   if (!dst_dev || !src_host || !pinned || bytes == 0 || n_threads < 1 || n_threads > 64) return CRA5_ERR_ARG;
   if (chunk_bytes < (1u << 16)) chunk_bytes = 1u << 16;
   n_threads = cap_threads(n_threads);
-  const Slices S{bytes, chunk_bytes, n_threads};
+  const Slices S(bytes, chunk_bytes, n_threads, true);
   const size_t nc = S.n_chunks();
   std::vector<std::atomic<int>> done(nc);
   for (auto &d : done) d.store(0, std::memory_order_relaxed);
@@ -88,7 +103,7 @@ extern "C" int cra5_copy_h2d_staged(void *dst_dev, const void *src_host, void *p
     if (hi > lo) std::memcpy(static_cast<char *>(pinned) + lo, static_cast<const char *>(src_host) + lo, hi - lo);
     done[c].fetch_add(1, std::memory_order_release);
     for (Backoff b; done[c].load(std::memory_order_acquire) < n_threads;) b.wait();
-    const size_t c0 = c * chunk_bytes, len = (c0 + chunk_bytes <= bytes ? chunk_bytes : bytes - c0);
+    const size_t c0 = S.offset(c), len = S.length(c);
     if (!rc)
       rc = (int)hipMemcpyAsync(static_cast<char *>(dst_dev) + c0, static_cast<const char *>(pinned) + c0, len,
                                hipMemcpyHostToDevice, st);
@@ -112,13 +127,13 @@ extern "C" int cra5_copy_d2h_staged(void *dst_host, const void *src_dev, void *p
   if (!dst_host || !src_dev || !pinned || bytes == 0 || n_threads < 1 || n_threads > 64) return CRA5_ERR_ARG;
   if (chunk_bytes < (1u << 16)) chunk_bytes = 1u << 16;
   n_threads = cap_threads(n_threads);
-  const Slices S{bytes, chunk_bytes, n_threads};
+  const Slices S(bytes, chunk_bytes, n_threads, false);
   const size_t nc = S.n_chunks();
   hipStream_t st = static_cast<hipStream_t>(stream);
   std::vector<hipEvent_t> ev(nc, nullptr);
   int rc = 0;
   for (size_t c = 0; c < nc && !rc; ++c) {
-    const size_t c0 = c * chunk_bytes, len = (c0 + chunk_bytes <= bytes ? chunk_bytes : bytes - c0);
+    const size_t c0 = S.offset(c), len = S.length(c);
     rc = (int)hipEventCreateWithFlags(&ev[c], hipEventDisableTiming);
     if (!rc)
       rc = (int)hipMemcpyAsync(static_cast<char *>(pinned) + c0, static_cast<const char *>(src_dev) + c0, len,
