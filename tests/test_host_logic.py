@@ -99,6 +99,9 @@ def test_bin_container_byte_layout():
     assert blob == expect
     strings, shape = binfmt.unpack_bin(blob)
     assert strings == [[b"\x01\x02\x03\x04YYYY"], [b"ZZ"]] and shape == (18, 36)
+    g = io.BytesIO()
+    binfmt.write_bin(g, [[b"\x01\x02\x03\x04YYYY"], [b"ZZ"]], (18, 36))        # the copy-free writer: the same bytes
+    assert g.getvalue() == expect
     f = io.BytesIO()
     assert binfmt.write_uints(f, (1, 2)) == 8 and binfmt.write_bytes(f, b"abc") == 3
     f.seek(0)
