@@ -19,7 +19,6 @@ There is no CPU path: on a non-GPU device every compute method raises.
 """
 import contextlib
 import math
-import os
 import threading
 import time
 from collections import OrderedDict

@@ -6,7 +6,7 @@ cra5_rans_encode_resolved_compact, cra5_rans_encode_with_indexes, cra5_rans_deco
 Streams: "default" = build_variants/frame_symbols.npz when present (a real frame of the default synthetic-weight model:
 4.3 MB, 37 % of the symbols escape-coded), "matched" = a seeded stream in a trained model's regime (1 MB, no escapes).
 Every library must write the same bytes."""
-import ctypes, os, sys, time, subprocess
+import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa
