@@ -1072,27 +1072,35 @@ class VAEformer(nn.Module):
         # the z stream is coded beside the y stream (round 6): two independent coders, the native calls release the GIL -
         # 2 ms off the serial host phase of every frame (16.5 ms with the default synthetic weights, 8.5 entropy-matched)
         z_job = self._z_pool().submit(self._encode_z, z_sym.numpy().reshape(-1), (1, z_sym.shape[0], z_sym.shape[1]))   # (joined below)
-        if host[0] == "compact" and int(host[3][0]) != 0:
-            # an escape payload beyond 12 bits (|symbol| thousands beyond its table row): this frame takes the 32-bit records
-            with self._gpu_phase(light=True):
-                sr, raw, esc = ops.rans_resolve_symbols(keep["sym"].reshape(-1), keep["idx"].reshape(-1),
-                                                        gc._quantized_cdf, gc._cdf_length, gc._offset)
-                host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
-        keep.clear()
-        if host[0] == "compact":
-            rec_np = host[2].numpy()
-            y_str = ops.rans_encode_resolved_compact(host[1].numpy(), rec_np)
-            n_esc = int(np.count_nonzero(rec_np))
-        elif host[0] == "resolved":
-            esc_np = host[3].numpy()
-            y_str = ops.rans_encode_resolved(host[1].numpy(), host[2].numpy(), esc_np)
-            n_esc = int(np.count_nonzero(esc_np))
-        else:
-            sym_np, idx_np = host[1].numpy().reshape(-1), host[2].numpy().reshape(-1)
-            y_str = gc.encode_symbols(sym_np, idx_np)
-            _, ln, off = gc.host_tables()
-            v = sym_np - off[idx_np]
-            n_esc = int(np.count_nonzero((v < 0) | (v >= ln[idx_np] - 2)))
+        try:
+            if host[0] == "compact" and int(host[3][0]) != 0:
+                # an escape payload beyond 12 bits (|symbol| thousands beyond its table row): this frame takes the 32-bit records
+                with self._gpu_phase(light=True):
+                    sr, raw, esc = ops.rans_resolve_symbols(keep["sym"].reshape(-1), keep["idx"].reshape(-1),
+                                                            gc._quantized_cdf, gc._cdf_length, gc._offset)
+                    host = ("resolved", self._to_host("y_sr", sr), self._to_host("y_raw", raw), self._to_host("y_esc", esc))
+            keep.clear()
+            if host[0] == "compact":
+                rec_np = host[2].numpy()
+                y_str = ops.rans_encode_resolved_compact(host[1].numpy(), rec_np)
+                n_esc = int(np.count_nonzero(rec_np))
+            elif host[0] == "resolved":
+                esc_np = host[3].numpy()
+                y_str = ops.rans_encode_resolved(host[1].numpy(), host[2].numpy(), esc_np)
+                n_esc = int(np.count_nonzero(esc_np))
+            else:
+                sym_np, idx_np = host[1].numpy().reshape(-1), host[2].numpy().reshape(-1)
+                y_str = gc.encode_symbols(sym_np, idx_np)
+                _, ln, off = gc.host_tables()
+                v = sym_np - off[idx_np]
+                n_esc = int(np.count_nonzero((v < 0) | (v >= ln[idx_np] - 2)))
+        except BaseException:
+            z_job.cancel()
+            try:
+                z_job.result()          # (the z coder reads this thread's pinned record buffer: let it finish before we leave)
+            except BaseException:  # noqa: BLE001
+                pass
+            raise
         z_str = z_job.result()
         # symbols of the y stream coded through the escape path (rans_interface.cpp:120-160): the SURVEY 8(e) stats field
         self._tls.last_n_escape = n_esc
