@@ -42,6 +42,18 @@ for form in ("classic", "persistent"):
         pro, loop, epi = us(t[:, 1] - t[:, 0]), us(t[:, 2] - t[:, 1]), us(t[:, 3] - t[:, 2])
         ghz = t[:, 5] / np.maximum(1, (t[:, 3] - t[:, 0]) * 10.0)
         print(f"--- {form}, {'reduced precision' if hi else 'fp32-accurate'}: {len(t)} rows, launch span {span:.1f} us, clock {np.median(ghz):.2f} GHz")
+        dur = us(t[:, 3] - t[:, 0])
+        st = us(t[:, 0] - t[:, 0].min())
+        q = lambda a, p: float(np.percentile(a, p))  # noqa: E731
+        print(f"    duration per row: p5 {q(dur, 5):.1f} p50 {q(dur, 50):.1f} p95 {q(dur, 95):.1f} max {dur.max():.1f} us; "
+              f"rows starting in the first 2 us: {int((st < 2).sum())}, duration of those p50 {q(dur[st < 2], 50):.1f} p95 {q(dur[st < 2], 95):.1f} "
+              f"max {dur[st < 2].max():.1f}; later rows: start p5 {q(st[st >= 2], 5) if (st >= 2).any() else 0:.1f} p50 "
+              f"{q(st[st >= 2], 50) if (st >= 2).any() else 0:.1f} p95 {q(st[st >= 2], 95) if (st >= 2).any() else 0:.1f}, duration p50 "
+              f"{q(dur[st >= 2], 50) if (st >= 2).any() else 0:.1f} p95 {q(dur[st >= 2], 95) if (st >= 2).any() else 0:.1f}")
+        for nm, m in (("first round (start < 2 us)", st < 2), ("later rows", st >= 2)):
+            if m.any():
+                print(f"    {nm}: prologue p50 {q(pro[m], 50):.2f} us, key loop p50 {q(loop[m], 50):.2f} = {q(loop[m], 50) / max(1, np.median(t[m, 4] % 1000)):.2f} us / step, "
+                      f"epilogue p50 {q(epi[m], 50):.2f}")
         for kind in sorted(set(t[:, 4])):
             m = t[:, 4] == kind
             nt = kind % 1000
