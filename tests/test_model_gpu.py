@@ -1012,6 +1012,23 @@ def test_api_batch_methods_pinned_pipeline(thin, dev, tmp_path):
                                 data=[f64, torch.from_numpy(frames[2]), strided], save_root=str(tmp_path / "alt"), workers=2)
     want = open(res[2]["save_path"], "rb").read()
     assert all(open(r["save_path"], "rb").read() == want for r in alt)
+    # the link gate (round 6: one frame per direction on the host link at a time) is scheduling, not arithmetic: with it
+    # off, and with out= copy teams, the same files and reconstructions come back; bad `out=` arrays are refused
+    assert api.link_serial is True and api.runtime.link_serial is True
+    api.link_serial = False
+    try:
+        rt2 = api.roundtrip_batch(stamps, data=frames, save_root=str(tmp_path / "RT2"), workers=3)
+    finally:
+        api.link_serial = True
+    for i in range(5):
+        assert open(rt2[i][0]["save_path"], "rb").read() == open(res[i]["save_path"], "rb").read()
+        assert np.array_equal(rt2[i][1], out[i])
+    for bad in (np.empty((5, 8, 721, 1440), dtype=np.float64), np.empty((4, 8, 721, 1440), dtype=np.float32),
+                np.empty((5, 8, 1440, 721), dtype=np.float32).transpose(0, 1, 3, 2)):
+        with pytest.raises(ValueError):
+            api.decode_batch(stamps, out=bad, workers=2)
+        with pytest.raises(ValueError):
+            api.roundtrip_batch(stamps, data=frames, save_root=str(tmp_path / "RT3"), workers=2, out=bad)
 
 
 def test_hyper_prior_engine_is_pinned_across_engine_settings(thin, thin_side, dev):
