@@ -54,6 +54,18 @@ def test_bench_json_contract(bench_line):
     assert m["escape_symbols_per_frame"] < 0.01 * 256 * 72 * 144 < d["escape_symbols_per_frame"]
     a = d["api_pipelined"]
     assert a["value"] > 0 and a["encode_fps"] > 0 and a["decode_fps"] > 0 and a["bin_equals_serial_api_call"] is True
+    # round 6: the settings object and the preflight travel with the line, every rank reports its own rate / clock / host
+    # phases, the single-frame API sample carries a budget whose terms add up to its totals
+    rt, pre = d["config"]["runtime"], d["config"]["preflight"]
+    assert rt["precision"] == "fp32" and rt["gemm_engine"] == "split" and rt["link_serial"] is True and rt["native_library"] == "libcra5_amd.so"
+    assert pre["inflight_requested"] == pre["inflight"] == d["config"]["frames_in_flight_per_gpu"] and pre["per_rank"][0]["free_gib"] > 50
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and d["per_rank"][0]["value"] >= d["value"] * 0.99
+    b = d["api_single_frame"]["budget_ms"]
+    assert abs(b["encode_total"] - sum(b[k] for k in ("h2d", "g1_g_a_and_latent_side", "g1b_other_gpu_phases", "h1_rans_encode",
+                                                       "bin_write", "encode_other"))) < 1e-6
+    assert b["h2d"] > 5 and b["h1_rans_encode"] > 0 and b["h2y_rans_decode_y"] > 0 and abs(b["encode_other"]) < 0.1 * b["encode_total"]
+    assert d["api_single_frame"]["entropy_matched_weights"]["frames_per_s"] > d["api_single_frame"]["budget_ms"]["frames_per_s"]
+    assert a["link_serial"] is True
     pin = d["reference_pinned_frames"]
     assert pin and set(pin) == {"1000", "1001"} and all(v["z_bytes"] == v["z_bytes_reference"] for v in pin.values())
     assert all(abs(v["y_bytes"] - v["y_bytes_reference"]) <= 256 for v in pin.values())
